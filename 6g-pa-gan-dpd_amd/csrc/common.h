@@ -1,0 +1,85 @@
+// Shared device helpers and host-side error plumbing for libdpd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/dpd_hip.h"
+
+// ---- host side -------------------------------------------------------------------------
+void dpd_set_error(const char *fmt, ...);
+
+#define DPD_REQUIRE(cond, code, ...)        \
+    do {                                    \
+        if (!(cond)) {                      \
+            dpd_set_error(__VA_ARGS__);     \
+            return (code);                  \
+        }                                   \
+    } while (0)
+
+#define DPD_HIP(expr)                                                                     \
+    do {                                                                                  \
+        hipError_t e_ = (expr);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            dpd_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return DPD_ERR_HIP;                                                           \
+        }                                                                                 \
+    } while (0)
+
+#define DPD_LAUNCH_CHECK() DPD_HIP(hipGetLastError())
+
+static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Blocks for a grid-stride kernel: enough to fill 256 CUs several times over, never more than the work.
+static inline int grid_for(int64_t items, int per_block, int max_blocks = 256 * 8) {
+    int64_t b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > max_blocks) b = max_blocks;
+    return (int)b;
+}
+
+// ---- generator flat layout --------------------------------------------------------------
+constexpr int G_W1 = 0, G_B1 = 960, G_W2 = 992, G_B2 = 1504, G_W3 = 1520, G_B3 = 1552;
+constexpr int G_NP = DPD_GEN_NPARAM;
+constexpr int G_SLAB = 1560;  // one partial-gradient row: 1554 gradients, [1554] = loss partial, padding
+
+// critic flat layout
+constexpr int C_W1 = 0, C_B1 = 256, C_W2 = 320, C_B2 = 2368, C_W3 = 2400, C_B3 = 2912, C_W4 = 2928, C_B4 = 2944;
+constexpr int C_NP = DPD_CRITIC_NPARAM;
+constexpr int C_SLAB = 2952;  // 2945 gradients + padding
+
+// ---- device helpers ---------------------------------------------------------------------
+#define DEV __device__ __forceinline__
+
+DEV float scale_of(float amax, float qmax = 32767.0f) { return fmaxf(amax, 1e-8f) / qmax; }
+
+// quantise-dequantise with a given scale: clamp(rint(v / s), -2^15, 2^15 - 1) * s  (true division,
+// round-half-even: same arithmetic as the reference's StraightThroughQuantize)
+DEV float fq16(float v, float s) {
+    float q = rintf(v / s);
+    q = fminf(fmaxf(q, -32768.0f), 32767.0f);
+    return q * s;
+}
+
+DEV float lrelu(float v, float slope) { return v > 0.0f ? v : v * slope; }
+DEV float lrelu_mask(float z, float slope) { return z > 0.0f ? 1.0f : slope; }
+
+DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+DEV double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// atomic max for non-negative floats (bit pattern order == value order)
+DEV void atomic_max_nonneg(float *addr, float v) {
+    atomicMax(reinterpret_cast<unsigned int *>(addr), __float_as_uint(v));
+}

@@ -1,0 +1,134 @@
+// C ABI of the generator path: argument checks, kernel-family dispatch, multi-pass QAT driver.
+#include "gen_internal.h"
+
+int gen_launch_prepare(const float *, const float *, const float *, const float *, const float *, const float *, int,
+                       float *, float *, hipStream_t);
+int gen_launch_taps(const float *, int64_t, int64_t, float *, hipStream_t);
+int gen_launch_quantize_output(float *, int64_t, const float *, hipStream_t);
+
+namespace {
+
+constexpr int64_t MFMA_MIN_SAMPLES = 4096;  // below this the VALU kernels win on launch geometry
+
+int make_problem(GenProblem &p, const float *x, int64_t B, int64_t S, int pre, const float *wq, float slope, int qat,
+                 float *absmax) {
+    DPD_REQUIRE(x && wq, DPD_ERR_INVALID_ARG, "generator: null input or weight pointer");
+    DPD_REQUIRE(B >= 0, DPD_ERR_INVALID_ARG, "generator: negative batch %lld", (long long)B);
+    if (!pre) DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
+    DPD_REQUIRE(!qat || absmax, DPD_ERR_INVALID_ARG, "generator: QAT needs the absmax buffer");
+    p.x = x; p.B = B; p.S = pre ? 0 : S; p.L = pre ? 1 : S - DPD_GEN_MEMORY; p.N = B * p.L;
+    p.pre = pre != 0; p.qat = qat != 0; p.wq = wq; p.slope = slope; p.absmax = absmax;
+    return DPD_OK;
+}
+
+bool use_mfma(const GenProblem &p, int impl) {
+    if (p.pre) return false;
+    if (impl == DPD_IMPL_MFMA) return true;
+    if (impl == DPD_IMPL_VALU) return false;
+    return p.N >= MFMA_MIN_SAMPLES;
+}
+
+int forward_dispatch(const GenProblem &p, int depth, float *out, int impl, hipStream_t st) {
+    if (p.N == 0) return DPD_OK;
+    return use_mfma(p, impl) ? gen_mfma_forward(p, depth, out, st) : gen_valu_forward(p, depth, out, st);
+}
+
+}  // namespace
+
+extern "C" size_t dpd_workspace_bytes(int64_t n_samples) {
+    (void)n_samples;
+    // partial-gradient slabs: at most 2048 rows of max(G_SLAB, C_SLAB) floats, plus reduction scratch
+    return (size_t)2048 * C_SLAB * sizeof(float) + (size_t)(1 << 20);
+}
+
+extern "C" int dpd_tap_assembly(const float *iq, int64_t B, int64_t S, float *feat, void *stream) {
+    DPD_REQUIRE(iq && feat, DPD_ERR_INVALID_ARG, "tap_assembly: null pointer");
+    DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
+    if (B <= 0) return DPD_OK;
+    return gen_launch_taps(iq, B, S, feat, as_stream(stream));
+}
+
+extern "C" int dpd_gen_prepare_weights(const float *w1, const float *b1, const float *w2, const float *b2,
+                                       const float *w3, const float *b3, int qat, float *wq, float *absmax,
+                                       void *stream) {
+    DPD_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && wq && absmax, DPD_ERR_INVALID_ARG, "prepare_weights: null pointer");
+    return gen_launch_prepare(w1, b1, w2, b2, w3, b3, qat, wq, absmax, as_stream(stream));
+}
+
+extern "C" int dpd_gen_absmax_pass(int stage, const float *x, int64_t B, int64_t S, int pre_assembled,
+                                   const float *wq, float slope, float *absmax, float *out, int impl, void *stream) {
+    DPD_REQUIRE(stage >= 0 && stage <= 3, DPD_ERR_INVALID_ARG, "absmax_pass: stage %d not in 0..3", stage);
+    GenProblem p;
+    int rc = make_problem(p, x, B, S, pre_assembled, wq, slope, 1, absmax);
+    if (rc) return rc;
+    DPD_REQUIRE(stage < 3 || out, DPD_ERR_INVALID_ARG, "absmax_pass: stage 3 writes the output, out is null");
+    hipStream_t st = as_stream(stream);
+    DPD_HIP(hipMemsetAsync(absmax + stage, 0, sizeof(float), st));
+    return forward_dispatch(p, stage, out, impl, st);
+}
+
+extern "C" int dpd_gen_quantize_output(float *out, int64_t n, const float *absmax, void *stream) {
+    DPD_REQUIRE(out && absmax && n >= 0, DPD_ERR_INVALID_ARG, "quantize_output: bad argument");
+    if (n == 0) return DPD_OK;
+    return gen_launch_quantize_output(out, n, absmax, as_stream(stream));
+}
+
+extern "C" int dpd_gen_forward(const float *x, int64_t B, int64_t S, int pre_assembled, const float *wq, float slope,
+                               int qat, float *absmax, float *out, int impl, void *stream) {
+    GenProblem p;
+    int rc = make_problem(p, x, B, S, pre_assembled, wq, slope, qat, absmax);
+    if (rc) return rc;
+    DPD_REQUIRE(out, DPD_ERR_INVALID_ARG, "gen_forward: out is null");
+    hipStream_t st = as_stream(stream);
+    if (!p.qat) return forward_dispatch(p, 4, out, impl, st);
+    DPD_HIP(hipMemsetAsync(absmax, 0, 4 * sizeof(float), st));
+    for (int stage = 0; stage < 4; ++stage) {
+        rc = forward_dispatch(p, stage, out, impl, st);
+        if (rc) return rc;
+    }
+    if (p.N == 0) return DPD_OK;
+    return gen_launch_quantize_output(out, p.N * 2, absmax, st);
+}
+
+static int backward_common(const GenProblem &p, const float *grad_out, const float *target, float *grads, float *loss,
+                           float *grad_feat, void *ws, size_t ws_bytes, int impl, hipStream_t st) {
+    DPD_REQUIRE(grads, DPD_ERR_INVALID_ARG, "gen_backward: grads is null");
+    DPD_REQUIRE(ws && ws_bytes >= dpd_workspace_bytes(p.N), DPD_ERR_WORKSPACE,
+                "gen_backward: workspace of %zu bytes needed, %zu given", dpd_workspace_bytes(p.N), ws_bytes);
+    if (p.N == 0) {
+        DPD_HIP(hipMemsetAsync(grads, 0, G_NP * sizeof(float), st));
+        if (loss) DPD_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+        return DPD_OK;
+    }
+    float *slab = reinterpret_cast<float *>(ws);
+    int n_partials = 0, rc;
+    if (use_mfma(p, impl)) {
+        DPD_REQUIRE(grad_feat == nullptr, DPD_ERR_INVALID_ARG, "gen_backward: grad_feat needs pre-assembled input");
+        rc = gen_mfma_backward(p, grad_out, target, slab, &n_partials, st);
+    } else {
+        rc = gen_valu_backward(p, grad_out, target, grad_feat, slab, &n_partials, st);
+    }
+    if (rc) return rc;
+    return gen_reduce_slab(slab, n_partials, grads, loss, 1.0f / (2.0f * (float)p.N), st);
+}
+
+extern "C" int dpd_gen_backward(const float *x, int64_t B, int64_t S, int pre_assembled, const float *wq, float slope,
+                                int qat, const float *absmax, const float *grad_out, float *grads, float *grad_feat,
+                                void *ws, size_t ws_bytes, int impl, void *stream) {
+    GenProblem p;
+    int rc = make_problem(p, x, B, S, pre_assembled, wq, slope, qat, const_cast<float *>(absmax));
+    if (rc) return rc;
+    DPD_REQUIRE(grad_out, DPD_ERR_INVALID_ARG, "gen_backward: grad_out is null");
+    DPD_REQUIRE(!grad_feat || p.pre, DPD_ERR_INVALID_ARG, "gen_backward: grad_feat needs pre-assembled input");
+    return backward_common(p, grad_out, nullptr, grads, nullptr, grad_feat, ws, ws_bytes, impl, as_stream(stream));
+}
+
+extern "C" int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const float *target, const float *wq,
+                                float slope, int qat, const float *absmax, float *grads, float *loss, void *ws,
+                                size_t ws_bytes, int impl, void *stream) {
+    GenProblem p;
+    int rc = make_problem(p, iq, B, S, 0, wq, slope, qat, const_cast<float *>(absmax));
+    if (rc) return rc;
+    DPD_REQUIRE(target && loss, DPD_ERR_INVALID_ARG, "gen_mse_step: null target or loss");
+    return backward_common(p, nullptr, target, grads, loss, nullptr, ws, ws_bytes, impl, as_stream(stream));
+}

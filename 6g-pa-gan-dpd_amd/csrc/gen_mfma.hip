@@ -1,0 +1,498 @@
+// Generator kernels, MFMA family (gfx950): tap assembly + 30->32->16->2 forward (+ backward) fused
+// per 16-sample tile on v_mfma_f32_16x16x4_f32.  Reference semantics as in gen_valu.hip.
+//
+// Geometry.  A wave owns a chunk of 64 consecutive output samples of one IQ row (4 tiles of 16).
+// Lane l = (g = l >> 4, j = l & 15).  Every product is computed transposed, D = W * X^T, so that
+// the sample index sits on the MFMA column (lane j) and the neuron index on the rows: a 16x16
+// result tile leaves lane (g, j) holding neurons 4g..4g+3 of sample j, which is exactly the B
+// operand layout (k = lane group) of the next layer's MFMA; no lane movement between layers.
+//
+// FC1 contracts over 32 "slots" (30 features + 2 zeros) in this kernel's own order
+//   slot = 6 * type + tap,  type 0..4 = I, Q, |x|, |x|^2, |x|^4,  tap 0..5
+// with the W1 columns gathered to match.  The five per-time-point series of a chunk live in LDS
+// (69 points each); a feature operand is one ds_read_b32 at series[type][j + 5 - tap].
+//
+// The weight gradient contracts over samples, so samples must move from lanes to the MFMA K axis:
+// gz1, h1 and gz2 go through XOR-swizzled wave-private LDS tiles ([sample][neuron]); the x operand
+// of dW1 is read straight from the series.  FC3 (2 outputs), its gradient and all bias gradients
+// stay on the VALU with per-lane accumulators that are reduced once at the end of the kernel.
+// All LDS traffic is wave-private, so there are no workgroup barriers: LDS operations of one wave
+// execute in program order.
+#include "gen_internal.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVES = 4;
+constexpr int CHUNK = 64;           // samples per wave iteration
+constexpr int SER_STRIDE = 71;      // words between series (71 = 7 mod 32: bank-disjoint operand reads)
+constexpr int SER_BASE0 = 5;
+constexpr int ZERO_W = 360;         // a word that always holds 0 (slots 30, 31)
+constexpr int SER_WORDS = 368;
+constexpr int P32 = 48;             // row pitch of the 32-column transposition tiles (16 mod 32)
+constexpr int P16 = 16;
+constexpr int GZ1_W = SER_WORDS;                 // 16 x 48
+constexpr int H1_W = GZ1_W + 16 * P32;           // 16 x 48
+constexpr int GZ2_W = H1_W + 16 * P32;           // 16 x 16
+constexpr int BWD_WORDS = GZ2_W + 16 * P16;      // 2160 words per wave
+
+DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+// reference feature index (models/tdnn_generator.py:176-193) of a slot; -1 for the two zero slots
+DEV int slot_ref(int slot) {
+    if (slot >= 30) return -1;
+    int type = slot / 6, tap = slot - 6 * type;
+    if (type == 0) return tap == 0 ? 0 : 20 + 2 * (tap - 1);
+    if (type == 1) return tap == 0 ? 1 : 21 + 2 * (tap - 1);
+    return 2 + 6 * (type - 2) + tap;
+}
+// word offset inside the series region of (slot, sample 0 of tile 0); add sample index and 16 * tile
+DEV int slot_word(int slot) {
+    if (slot >= 30) return ZERO_W;
+    int type = slot / 6, tap = slot - 6 * type;
+    return SER_BASE0 + SER_STRIDE * type + 5 - tap;
+}
+DEV int swz(int s) { return 4 * ((s >> 1) & 3); }
+
+struct Lane {
+    int lane, j, g;
+};
+
+// Load the chunk's 69 IQ points, derive the five series and park them in LDS.
+template <bool QAT>
+DEV void stage_series(float *ser, const float2 *__restrict__ iqrow, int64_t t0, int64_t S, int lane, float s0) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        int tau = lane + 64 * rep;
+        if (rep == 1 && lane >= 5) break;
+        int64_t idx = t0 + tau;
+        float2 v = make_float2(0.f, 0.f);
+        if (idx < S) v = iqrow[idx];
+        float e = sqrtf(v.x * v.x + v.y * v.y);
+        float e2 = e * e;
+        float e4 = e2 * e2;
+        if (QAT) {
+            v.x = fq16(v.x, s0);
+            v.y = fq16(v.y, s0);
+            e = fq16(e, s0);
+            e2 = fq16(e2, s0);
+            e4 = fq16(e4, s0);
+        }
+        float *p = ser + SER_BASE0 + tau;
+        p[0] = v.x;
+        p[SER_STRIDE] = v.y;
+        p[2 * SER_STRIDE] = e;
+        p[3 * SER_STRIDE] = e2;
+        p[4 * SER_STRIDE] = e4;
+    }
+}
+
+struct FwdWeights {
+    float A1[2][8];   // W1 tile t, step s: lane (i, g) holds W1[16t + i][slot 4s + g]
+    float A2[2][4];   // W2[i][16t + 4g + r]
+    float w3[2][4];   // W3[o][4g + r]
+    f32x4 bias1[2];   // b1[16t + 4g + r]
+    f32x4 bias2;      // b2[4g + r]
+    float b3[2];
+};
+
+DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, int g) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            int ref = slot_ref(4 * s + g);
+            w.A1[t][s] = ref >= 0 ? wq[G_W1 + (16 * t + j) * 30 + ref] : 0.f;
+        }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.A2[t][r] = wq[G_W2 + j * 32 + 16 * t + 4 * g + r];
+#pragma unroll
+    for (int o = 0; o < 2; ++o)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.w3[o][r] = wq[G_W3 + o * 16 + 4 * g + r];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.bias1[t][r] = wq[G_B1 + 16 * t + 4 * g + r];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w.bias2[r] = wq[G_B2 + 4 * g + r];
+    w.b3[0] = wq[G_B3];
+    w.b3[1] = wq[G_B3 + 1];
+}
+
+struct TileFwd {
+    f32x4 z1[2];   // pre-activations (sign gives the LeakyReLU mask)
+    f32x4 h1[2];   // activations as fed to FC2 (quantised when QAT)
+    f32x4 z2;
+    f32x4 h2;
+    float y[2];    // tanh output, identical in the four lanes of a sample
+};
+
+// Forward of one 16-sample tile.  DEPTH limits how far it runs (1: through act1, 2: through act2,
+// >= 3: to the output).  boff[s] = byte offset of this lane's FC1 operand for step s in tile 0.
+template <bool QAT, int DEPTH>
+DEV void tile_forward(TileFwd &tf, const FwdWeights &w, const char *ser_bytes, const int (&boff)[8], int tile,
+                      float slope, float s1, float s2) {
+    f32x4 a0 = w.bias1[0], a1 = w.bias1[1];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        float b = *reinterpret_cast<const float *>(ser_bytes + boff[s] + 64 * tile);
+        a0 = mfma4(w.A1[0][s], b, a0);
+        a1 = mfma4(w.A1[1][s], b, a1);
+    }
+    tf.z1[0] = a0;
+    tf.z1[1] = a1;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float h = lrelu(tf.z1[t][r], slope);
+            tf.h1[t][r] = (QAT && DEPTH >= 2) ? fq16(h, s1) : h;
+        }
+    if (DEPTH < 2) return;
+    f32x4 c0 = w.bias2, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        c0 = mfma4(w.A2[0][r], tf.h1[0][r], c0);
+        c1 = mfma4(w.A2[1][r], tf.h1[1][r], c1);
+    }
+    tf.z2 = c0 + c1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float h = lrelu(tf.z2[r], slope);
+        tf.h2[r] = (QAT && DEPTH >= 3) ? fq16(h, s2) : h;
+    }
+    if (DEPTH < 3) return;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        float p = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p = __builtin_fmaf(w.w3[o][r], tf.h2[r], p);
+        p += __shfl_xor(p, 16);
+        p += __shfl_xor(p, 32);
+        tf.y[o] = tanhf(p + w.b3[o]);
+    }
+}
+
+template <bool QAT, int DEPTH>
+__global__ __launch_bounds__(WAVES * 64) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
+                                                             int64_t cpr, int64_t n_chunks,
+                                                             const float *__restrict__ wq, float slope,
+                                                             float *__restrict__ absmax, float2 *__restrict__ out) {
+    __shared__ float lds[WAVES][SER_WORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    float *ser = lds[wave];
+    if (lane == 0) ser[ZERO_W] = 0.f;
+    FwdWeights w;
+    load_fwd_weights(w, wq, j, g);
+    int boff[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        int slot = 4 * s + g;
+        boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
+    }
+    float s0 = 1.f, s1 = 1.f, s2 = 1.f;
+    if (QAT) {
+        s0 = scale_of(absmax[0]);
+        if (DEPTH >= 2) s1 = scale_of(absmax[1]);
+        if (DEPTH >= 3) s2 = scale_of(absmax[2]);
+    }
+    float amax = 0.f;
+    for (int64_t chunk = (int64_t)blockIdx.x * WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * WAVES) {
+        const int64_t row = chunk / cpr, t0 = (chunk - row * cpr) * CHUNK;
+        stage_series<QAT>(ser, iq + row * S, t0, S, lane, s0);
+        float2 ysel = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            // with zero-size tiles skipped the wave stays convergent: the bound is wave-uniform
+            if (t0 + 16 * c >= L) break;
+            TileFwd tf;
+            tile_forward<QAT, DEPTH>(tf, w, reinterpret_cast<const char *>(ser), boff, c, slope, s1, s2);
+            const bool valid = (t0 + 16 * c + j) < L;
+            if (QAT && DEPTH == 1) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) amax = fmaxf(amax, valid ? fabsf(tf.h1[t][r]) : 0.f);
+            } else if (QAT && DEPTH == 2) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) amax = fmaxf(amax, valid ? fabsf(tf.h2[r]) : 0.f);
+            } else {
+                if (QAT) amax = fmaxf(amax, valid ? fmaxf(fabsf(tf.y[0]), fabsf(tf.y[1])) : 0.f);
+                if (g == c) ysel = make_float2(tf.y[0], tf.y[1]);
+            }
+        }
+        if (DEPTH >= 3) {
+            int64_t t = t0 + lane;  // lane (g, j) holds sample 16g + j of the chunk
+            if (t < L) out[row * L + t] = ysel;
+        }
+    }
+    if (QAT) {
+        amax = wave_max(amax);
+        if (lane == 0) atomic_max_nonneg(absmax + DEPTH, amax);
+    }
+}
+
+// max over all time points of |I|, |Q|, |x|, |x|^2, |x|^4 == abs-max of the assembled feature tensor
+__global__ __launch_bounds__(256) void k_iq_absmax(const float2 *__restrict__ iq, int64_t n_points,
+                                                   float *__restrict__ absmax) {
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_points; i += (int64_t)gridDim.x * 256) {
+        float2 v = iq[i];
+        float e = sqrtf(v.x * v.x + v.y * v.y);
+        float e2 = e * e;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(e, fmaxf(e2, e2 * e2))));
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0) atomic_max_nonneg(absmax, m);
+}
+
+// ------------------------------------------------------------------------------------ backward
+template <bool QAT, bool MSE>
+__global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
+                                                             int64_t cpr, int64_t n_chunks,
+                                                             const float *__restrict__ wq, float slope,
+                                                             const float *__restrict__ absmax,
+                                                             const float2 *__restrict__ grad_out,
+                                                             const float2 *__restrict__ target, float mse_scale,
+                                                             float *__restrict__ slab) {
+    __shared__ __attribute__((aligned(16))) float lds[WAVES][BWD_WORDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    float *ser = lds[wave];
+    if (lane == 0) ser[ZERO_W] = 0.f;
+    FwdWeights w;
+    load_fwd_weights(w, wq, j, g);
+    float A2T[2][4];  // W2[4g + r][16t + i]
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) A2T[t][r] = wq[G_W2 + (4 * g + r) * 32 + 16 * t + j];
+    int boff[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        int slot = 4 * s + g;
+        boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
+    }
+    // dW1 A operand: lane (i = j, g) reads slot 16u + i of sample 4q + g
+    int aoff[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        int slot = 16 * u + j;
+        aoff[u] = 4 * (slot_word(slot) + (slot < 30 ? g : 0));
+    }
+    // transposition tiles: write addresses (row j) and read addresses (row 4q + g)
+    const int wr32 = 4 * (j * P32 + ((4 * g) ^ swz(j)));
+    const int wr16 = 4 * (j * P16 + ((4 * g) ^ swz(j)));
+    int rd32[4], rd16[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        int s = 4 * q + g;
+        rd32[q] = 4 * (s * P32 + (j ^ swz(s)));
+        rd16[q] = 4 * (s * P16 + (j ^ swz(s)));
+    }
+    char *gz1_b = reinterpret_cast<char *>(ser + GZ1_W);
+    char *h1_b = reinterpret_cast<char *>(ser + H1_W);
+    char *gz2_b = reinterpret_cast<char *>(ser + GZ2_W);
+
+    float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+    if (QAT) {
+        s0 = scale_of(absmax[0]);
+        s1 = scale_of(absmax[1]);
+        s2 = scale_of(absmax[2]);
+        s3 = scale_of(absmax[3]);
+    }
+    f32x4 dW1[2][2], dW2[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        dW2[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 2; ++t) dW1[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    float dW3[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 db1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+    f32x4 db2 = {0.f, 0.f, 0.f, 0.f};
+    float db3[2] = {0.f, 0.f};
+    float loss = 0.f;
+
+    for (int64_t chunk = (int64_t)blockIdx.x * WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * WAVES) {
+        const int64_t row = chunk / cpr, t0 = (chunk - row * cpr) * CHUNK;
+        stage_series<QAT>(ser, iq + row * S, t0, S, lane, s0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (t0 + 16 * c >= L) break;
+            TileFwd tf;
+            tile_forward<QAT, 3>(tf, w, reinterpret_cast<const char *>(ser), boff, c, slope, s1, s2);
+            const int64_t t = t0 + 16 * c + j;
+            const bool valid = t < L;
+            float g0 = 0.f, g1 = 0.f;
+            if (valid) {
+                if (MSE) {
+                    float o0 = QAT ? fq16(tf.y[0], s3) : tf.y[0], o1 = QAT ? fq16(tf.y[1], s3) : tf.y[1];
+                    float2 tg = target[row * L + t];
+                    float d0 = o0 - tg.x, d1 = o1 - tg.y;
+                    if (g == 0) loss += d0 * d0 + d1 * d1;
+                    g0 = d0 * mse_scale;
+                    g1 = d1 * mse_scale;
+                } else {
+                    float2 go = grad_out[row * L + t];
+                    g0 = go.x;
+                    g1 = go.y;
+                }
+            }
+            const float gz3_0 = g0 * (1.f - tf.y[0] * tf.y[0]), gz3_1 = g1 * (1.f - tf.y[1] * tf.y[1]);
+            if (g == 0) {
+                db3[0] += gz3_0;
+                db3[1] += gz3_1;
+            }
+            f32x4 gz2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dW3[0][r] = __builtin_fmaf(gz3_0, tf.h2[r], dW3[0][r]);
+                dW3[1][r] = __builtin_fmaf(gz3_1, tf.h2[r], dW3[1][r]);
+                float gh2 = __builtin_fmaf(gz3_1, w.w3[1][r], gz3_0 * w.w3[0][r]);
+                gz2[r] = gh2 * lrelu_mask(tf.z2[r], slope);
+            }
+            db2 += gz2;
+            // gh1^T = W2^T gz2^T  (two row tiles of 16 h1-neurons)
+            f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                e0 = mfma4(A2T[0][r], gz2[r], e0);
+                e1 = mfma4(A2T[1][r], gz2[r], e1);
+            }
+            f32x4 gz1[2];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                gz1[0][r] = e0[r] * lrelu_mask(tf.z1[0][r], slope);
+                gz1[1][r] = e1[r] * lrelu_mask(tf.z1[1][r], slope);
+            }
+            db1[0] += gz1[0];
+            db1[1] += gz1[1];
+            // lanes -> K axis: park [sample][neuron] tiles in LDS
+            *reinterpret_cast<f32x4 *>(gz1_b + wr32) = gz1[0];
+            *reinterpret_cast<f32x4 *>(gz1_b + wr32 + 64) = gz1[1];
+            *reinterpret_cast<f32x4 *>(h1_b + wr32) = tf.h1[0];
+            *reinterpret_cast<f32x4 *>(h1_b + wr32 + 64) = tf.h1[1];
+            *reinterpret_cast<f32x4 *>(gz2_b + wr16) = gz2;
+            __builtin_amdgcn_wave_barrier();
+            const char *ser_b = reinterpret_cast<const char *>(ser);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // samples 4q + g of this tile
+                float x0 = *reinterpret_cast<const float *>(ser_b + aoff[0] + 64 * c + 16 * q);
+                float x1 = *reinterpret_cast<const float *>(ser_b + aoff[1] + 64 * c + 16 * q);
+                float gza = *reinterpret_cast<const float *>(gz1_b + rd32[q]);
+                float gzb = *reinterpret_cast<const float *>(gz1_b + rd32[q] + 64);
+                dW1[0][0] = mfma4(x0, gza, dW1[0][0]);
+                dW1[0][1] = mfma4(x0, gzb, dW1[0][1]);
+                dW1[1][0] = mfma4(x1, gza, dW1[1][0]);
+                dW1[1][1] = mfma4(x1, gzb, dW1[1][1]);
+                float ha = *reinterpret_cast<const float *>(h1_b + rd32[q]);
+                float hb = *reinterpret_cast<const float *>(h1_b + rd32[q] + 64);
+                float g2 = *reinterpret_cast<const float *>(gz2_b + rd16[q]);
+                dW2[0] = mfma4(ha, g2, dW2[0]);
+                dW2[1] = mfma4(hb, g2, dW2[1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+
+    // ---- write this wave's partial gradient row
+    float *rowp = slab + ((int64_t)blockIdx.x * WAVES + wave) * G_SLAB;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int ref = slot_ref(16 * u + 4 * g + r);
+                if (ref >= 0) rowp[G_W1 + (16 * t + j) * 30 + ref] = dW1[u][t][r];
+            }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rowp[G_W2 + j * 32 + 16 * u + 4 * g + r] = dW2[u][r];
+    // per-lane accumulators: sum over the 16 sample lanes of each lane group
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dW3[0][r] += __shfl_xor(dW3[0][r], off);
+            dW3[1][r] += __shfl_xor(dW3[1][r], off);
+            db1[0][r] += __shfl_xor(db1[0][r], off);
+            db1[1][r] += __shfl_xor(db1[1][r], off);
+            db2[r] += __shfl_xor(db2[r], off);
+        }
+        db3[0] += __shfl_xor(db3[0], off);
+        db3[1] += __shfl_xor(db3[1], off);
+    }
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            rowp[G_W3 + 4 * g + r] = dW3[0][r];
+            rowp[G_W3 + 16 + 4 * g + r] = dW3[1][r];
+            rowp[G_B1 + 4 * g + r] = db1[0][r];
+            rowp[G_B1 + 16 + 4 * g + r] = db1[1][r];
+            rowp[G_B2 + 4 * g + r] = db2[r];
+        }
+        if (g == 0) {
+            rowp[G_B3] = db3[0];
+            rowp[G_B3 + 1] = db3[1];
+        }
+    }
+    loss = wave_sum(loss);
+    if (lane == 0) rowp[G_NP] = loss;
+}
+
+}  // namespace
+
+static int mfma_grid(int64_t n_chunks) {
+    int64_t blocks = (n_chunks + WAVES - 1) / WAVES;
+    if (blocks > 512) blocks = 512;  // 2 workgroups per CU
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st) {
+    const float2 *iq = reinterpret_cast<const float2 *>(p.x);
+    if (p.qat && depth == 0) {
+        const int64_t n_points = p.B * p.S;
+        hipLaunchKernelGGL(k_iq_absmax, dim3(grid_for(n_points, 256)), dim3(256), 0, st, iq, n_points, p.absmax);
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
+    const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
+    const dim3 grid(mfma_grid(n_chunks)), block(WAVES * 64);
+    float2 *o = reinterpret_cast<float2 *>(out);
+#define GO(Q, D) hipLaunchKernelGGL((k_gen_fwd_mfma<Q, D>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
+                                    p.slope, p.absmax, o)
+    if (!p.qat) GO(false, 4);
+    else if (depth == 1) GO(true, 1);
+    else if (depth == 2) GO(true, 2);
+    else GO(true, 3);
+#undef GO
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *target, float *slab, int *n_partials,
+                      hipStream_t st) {
+    const float2 *iq = reinterpret_cast<const float2 *>(p.x);
+    const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
+    const int gridn = mfma_grid(n_chunks);
+    *n_partials = gridn * WAVES;
+    const dim3 grid(gridn), block(WAVES * 64);
+    const bool mse = grad_out == nullptr;
+    const float mse_scale = mse ? (float)(2.0 / (2.0 * (double)p.N)) : 0.f;
+    const float2 *go = reinterpret_cast<const float2 *>(grad_out), *tg = reinterpret_cast<const float2 *>(target);
+#define GO(Q, M) hipLaunchKernelGGL((k_gen_bwd_mfma<Q, M>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
+                                    p.slope, p.absmax, go, tg, mse_scale, slab)
+    if (p.qat) { if (mse) GO(true, true); else GO(true, false); }
+    else       { if (mse) GO(false, true); else GO(false, false); }
+#undef GO
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}

@@ -1,0 +1,189 @@
+/*
+ * dpd_hip.h - C ABI of libdpd_hip.so: the batched DPD hot path on MI355X (gfx950).
+ *
+ * Every entry point takes plain device pointers and sizes; no framework types.  All tensor
+ * arguments are DEVICE (HBM) pointers to contiguous fp32 (or int16 where stated) unless the
+ * name starts with h_.  `stream` is a hipStream_t passed as void* (NULL = default stream).
+ * Calls are asynchronous on `stream`; no entry point synchronises the device or allocates
+ * memory: scratch is caller-provided (`ws`, size from dpd_workspace_bytes()).
+ *
+ * Return value: DPD_OK or a DPD_ERR_* code; dpd_last_error() gives the text for the calling
+ * thread.  DPD_ERR_SHAPE marks the conditions on which the reference raises ValueError.
+ *
+ * The reference (orpheus016/6g-pa-gan-dpd) has no FFI: its boundary is the Python API of
+ * models/ and utils/.  Each entry below names the reference function it replaces.
+ */
+#ifndef DPD_HIP_H
+#define DPD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPD_OK 0
+#define DPD_ERR_INVALID_ARG 1 /* null pointer, negative size, unsupported option */
+#define DPD_ERR_SHAPE 2       /* reference raises ValueError (sequence too short, bad state) */
+#define DPD_ERR_HIP 3         /* a HIP runtime call failed */
+#define DPD_ERR_WORKSPACE 4   /* workspace missing or too small */
+
+/* Generator geometry fixed by the reference defaults (models/tdnn_generator.py:218-245):
+ * memory depth 5, features 30, hidden 32 and 16, outputs 2. */
+#define DPD_GEN_MEMORY 5
+#define DPD_GEN_NFEAT 30
+#define DPD_GEN_NPARAM 1554 /* flat order: W1[32x30] b1[32] W2[16x32] b2[16] W3[2x16] b3[2] */
+#define DPD_GEN_NSCALE 8    /* absmax[0..3]: features, act1, act2, tanh out; [4..6]: W1, W2, W3 */
+
+/* Critic geometry (models/discriminator.py:59-93 defaults): 4 -> 64 -> 32 -> 16 -> 1. */
+#define DPD_CRITIC_NPARAM 2945 /* flat: W1[64x4] b1[64] W2[32x64] b2[32] W3[16x32] b3[16] W4[1x16] b4[1] */
+
+/* kernel selection for the generator entry points */
+#define DPD_IMPL_AUTO 0
+#define DPD_IMPL_VALU 1 /* one sample per lane, weights as scalar operands */
+#define DPD_IMPL_MFMA 2 /* fp32 MFMA tiles of 16 samples (IQ-row input only) */
+
+const char *dpd_last_error(void);
+int dpd_version(void);
+
+/* Scratch size in bytes that the ws-taking entry points need for a problem of n_samples. */
+size_t dpd_workspace_bytes(int64_t n_samples);
+
+/* ---------------------------------------------------------------- generator ------------- */
+
+/* MemoryTapAssembly.forward (models/tdnn_generator.py:158-195): iq [B,S,2] -> feat [B,S-5,30].
+ * DPD_ERR_SHAPE if S <= 5. */
+int dpd_tap_assembly(const float *iq, int64_t B, int64_t S, float *feat, void *stream);
+
+/* Weight preparation shared by every generator call: packs the six parameter tensors into the
+ * flat layout; with qat != 0 the weights are per-row fake-quantised (16 bit, scale = rowmax/32767,
+ * models/tdnn_generator.py:394-403 with :74-103); biases stay fp32.  absmax[4..6] receive the
+ * per-tensor |W| maxima used by the running-scale bookkeeping (:122-130). */
+int dpd_gen_prepare_weights(const float *w1, const float *b1, const float *w2, const float *b2,
+                            const float *w3, const float *b3, int qat, float *wq, float *absmax,
+                            void *stream);
+
+/* One abs-max pass of the QAT forward (the four per-tensor activation scales of
+ * TDNNGeneratorQAT.forward, models/tdnn_generator.py:412-456, are global reductions that each
+ * depend on the previous one).  stage 0: features -> absmax[0]; 1: act1 -> absmax[1];
+ * 2: act2 -> absmax[2]; 3: tanh output -> absmax[3] and the unquantised output into `out`.
+ * x is iq [B,S,2] (pre_assembled == 0) or features [B,30] (pre_assembled != 0, S ignored).
+ * absmax[stage] is overwritten; earlier entries are read.  Between passes a data-parallel caller
+ * may max-reduce absmax[stage] across ranks. */
+int dpd_gen_absmax_pass(int stage, const float *x, int64_t B, int64_t S, int pre_assembled,
+                        const float *wq, float slope, float *absmax, float *out, int impl, void *stream);
+
+/* Final step of the QAT forward: out = fake_quant(out, absmax[3]) in place over n floats. */
+int dpd_gen_quantize_output(float *out, int64_t n, const float *absmax, void *stream);
+
+/* TDNNGenerator.forward / TDNNGeneratorQAT.forward (models/tdnn_generator.py:257-287, :412-456).
+ * qat == 0: one fused kernel.  qat != 0: runs the four abs-max passes and the output quantiser on
+ * `stream` (single-GPU semantics: scales from this call's batch).  out [B,S-5,2] or [B,2]. */
+int dpd_gen_forward(const float *x, int64_t B, int64_t S, int pre_assembled, const float *wq, float slope,
+                    int qat, float *absmax, float *out, int impl, void *stream);
+
+/* Backward of the generator for an upstream gradient grad_out (same shape as out): recomputes the
+ * forward from x with the scales in absmax (straight-through estimator, tdnn_generator.py:68-71)
+ * and writes the flat parameter gradient grads[1554].  grad_feat (optional, pre_assembled only)
+ * receives d loss / d features [B,30]. */
+int dpd_gen_backward(const float *x, int64_t B, int64_t S, int pre_assembled, const float *wq, float slope,
+                     int qat, const float *absmax, const float *grad_out, float *grads, float *grad_feat,
+                     void *ws, size_t ws_bytes, int impl, void *stream);
+
+/* Stage-1 supervised step core (training_colab.ipynb code cell 14, "STAGE 1"): forward,
+ * MSE(out, target) and backward fused; nothing but grads[1554] and loss[0] (the mean squared
+ * error) is written.  With qat != 0 absmax must already hold the four scales (run
+ * dpd_gen_absmax_pass 0..3 first). */
+int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const float *target, const float *wq, float slope,
+                     int qat, const float *absmax, float *grads, float *loss,
+                     void *ws, size_t ws_bytes, int impl, void *stream);
+
+/* ---------------------------------------------------------------- PA twin --------------- */
+
+/* VolterraPA.forward (models/pa_digital_twin.py:125-170): x [B,S,2] -> y [B,S-M+1,2] with
+ * K odd orders (1,3,..,2K-1) and M taps; coef_re/coef_im [K,M] on the device.
+ * DPD_ERR_SHAPE if S < M.  K <= 8, M <= 16. */
+int dpd_pa_forward(const float *x, int64_t B, int64_t S, const float *coef_re, const float *coef_im,
+                   int K, int M, float *y, void *stream);
+
+/* Gradient of the above w.r.t. x for an upstream gy [B,S-M+1,2]; gx [B,S,2] is overwritten.
+ * d|x|/dx at x == 0 is 0, as in torch. */
+int dpd_pa_backward(const float *x, int64_t B, int64_t S, const float *coef_re, const float *coef_im,
+                    int K, int M, const float *gy, float *gx, void *stream);
+
+/* Fused chain iq -> generator -> PA twin (the validation chain of demo/video_demo.py:221-248):
+ * y [B, S-5-M+1, 2]; dpd_out (optional) also receives the generator output [B,S-5,2]. */
+int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
+                       const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
+                       float *dpd_out, float *y, void *stream);
+
+/* ---------------------------------------------------------------- critic ---------------- */
+
+/* Discriminator.forward (models/discriminator.py:103-136) given the already spectrally
+ * normalised weights wb (flat, DPD_CRITIC_NPARAM): score[n] for n < N rows of x [N,2], cond [N,2].
+ * score_sum (optional) receives sum_n score[n]. */
+int dpd_critic_forward(const float *x, const float *cond, int64_t N, const float *wb, float slope,
+                       float *score, float *score_sum, void *stream);
+
+/* Backward for an upstream gscore[N] (or, if gscore is NULL, the constant gconst for every row):
+ * grads[2945] w.r.t. wb and optionally gx [N,2] w.r.t. x. */
+int dpd_critic_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope,
+                        const float *gscore, float gconst, float *grads, float *gx,
+                        void *ws, size_t ws_bytes, void *stream);
+
+/* compute_gradient_penalty (models/discriminator.py:139-191) with its double backward fused:
+ * x_hat = alpha[b]*real + (1-alpha[b])*fake per batch row b (rows of L samples; L = 1 for [B,2]
+ * inputs), g = d sum D(x_hat, cond) / d x_hat, gp = mean_b (||g_b||_2 - 1)^2.
+ * Writes gp[0], the row norms rownorm[B] and grads[2945] = d gp / d wb (bias entries are zero). */
+int dpd_critic_gp(const float *real, const float *fake, const float *cond, const float *alpha,
+                  int64_t B, int64_t L, const float *wb, float slope, float *gp, float *rownorm,
+                  float *grads, void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------- spectral loss --------- */
+
+/* Per-row statistics behind compute_evm / compute_acpr / compute_nmse / SpectralLoss
+ * (utils/spectral_loss.py:24-167, :209-257) for pred, target [B,L,2]; L a power of two, 8..4096.
+ * band [3,L] uint8 masks (main, lower, upper) as produced from fftfreq (:103-110).
+ * stats [B,8]: sum|p-t|, sum|p-t|^2, sum|t|^2, P_main, P_lower, P_upper (of pred, |X|^2/L), 0, 0.
+ * target may be NULL (ACPR only): the first three entries are then 0. */
+int dpd_spectral_stats(const float *pred, const float *target, int64_t B, int64_t L,
+                       const uint8_t *band, float *stats, void *stream);
+
+/* Backward: dpred [B,L,2] = c_l1 * sign(p-t) + rowc[b,0] * (p-t) + (2/L) * IDFT_unnormalised(
+ * (rowc[b,1]*main + rowc[b,2]*lower + rowc[b,3]*upper) * X) with X = FFT(pred row b);
+ * rowc [B,4] holds the per-row chain-rule coefficients. */
+int dpd_spectral_backward(const float *pred, const float *target, int64_t B, int64_t L,
+                          const uint8_t *band, float c_l1, const float *rowc, float *dpred, void *stream);
+
+/* ---------------------------------------------------------------- fixed point ----------- */
+
+/* quantize_to_fixed_point / fake_quantize (utils/quantization.py:88-161): q = clamp(rint(x*scale),
+ * qmin, qmax); out = q (dequant == 0) or q/scale (dequant != 0). */
+int dpd_quantize_fixed(const float *x, int64_t n, float scale, int bits, int is_signed, int dequant,
+                       float *out, void *stream);
+
+/* fake_quantize with a data-derived scale (models/tdnn_generator.py:74-103): x [rows, cols];
+ * per_row == 0: one scale for the tensor, else one per row (rows <= 65535).  absmax_out [1] or [rows]
+ * is required: it is the reduction scratch and returns the abs-max values. */
+int dpd_fake_quantize_dynamic(const float *x, int64_t rows, int64_t cols, int per_row, int n_bits,
+                              float *out, float *absmax_out, void *stream);
+
+/* Bit-exact Q8.8 inference: iq int16 Q1.15 [B,S,2] -> out int16 Q1.15 [B,S-5,2].
+ * Weights int16 Q1.15 (w1 [32,30], w2 [16,32], w3 [2,16]), biases int16 Q8.8, accumulators Q9.23,
+ * requantisation round-half-even with saturation (utils/quantization.py:88-120, :213-256),
+ * tanh through the 256-entry table of generate_tanh_lut (:365-393).  acc64 != 0 forces 64-bit
+ * accumulators; acc64 == 0 requires dpd_q88_int32_safe() to hold for the weights. */
+int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int16_t *w1, const int16_t *b1,
+                  const int16_t *w2, const int16_t *b2, const int16_t *w3, const int16_t *b3,
+                  const int16_t *lut, int acc64, int16_t *out, void *stream);
+
+/* Host-side interval check (h_ = host pointers): 1 if 32-bit accumulation is provably exact for
+ * every input, 0 otherwise. */
+int dpd_q88_int32_safe(const int16_t *h_w1, const int16_t *h_b1, const int16_t *h_w2, const int16_t *h_b2,
+                       const int16_t *h_w3, const int16_t *h_b3);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPD_HIP_H */

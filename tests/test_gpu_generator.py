@@ -1,0 +1,176 @@
+"""GPU parity of the generator path (tap assembly, float and QAT forward/backward) against the
+golden fixtures and the CPU oracle.  Tolerances: tap indexing bit-exact; fp32 outputs rel <= 1e-5
+(atol 1e-6 for values near zero); fake-quantised outputs within one 16-bit step."""
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, T, close, close_q, load_golden, ofdm_rows, sd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dpd():
+    import dpd_amd
+    return dpd_amd
+
+
+def load_gen(dpd, params, qat_cls=True):
+    from dpd_amd.models import TDNNGenerator, TDNNGeneratorQAT
+    g = (TDNNGeneratorQAT if qat_cls else TDNNGenerator)()
+    g.load_state_dict({k: v for k, v in params.items()}, strict=False)
+    return g.to(DEV)
+
+
+def test_taps_bit_exact(dpd):
+    from dpd_amd.models import MemoryTapAssembly
+    g = load_golden("g1_taps")
+    mta = MemoryTapAssembly(5)
+    assert np.array_equal(mta(T(g["probe"])).cpu().numpy(), g["feat_probe"])
+    f = mta(T(g["iq"])).cpu().numpy()
+    mask = np.ones(30, bool); mask[14:20] = False
+    assert np.array_equal(f[..., mask], g["feat"][..., mask])
+    np.testing.assert_allclose(f[..., 14:20], g["feat"][..., 14:20], rtol=3e-7, atol=0)
+    with pytest.raises(ValueError):
+        mta(torch.zeros(1, 5, 2, device=DEV))
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+def test_float_generator_golden(dpd, impl):
+    from oracle import generator as og
+    g = load_golden("g2_float_gen")
+    gen = load_gen(dpd, sd(g, "sd__"), qat_cls=False)
+    gen.kernel_impl = impl
+    out = gen(T(g["iq"]))
+    close(out, g["out"], rtol=1e-5, atol=1e-6)
+    loss = torch.nn.functional.mse_loss(out, T(g["target"]))
+    loss.backward()
+    for k in og.PARAM_KEYS:
+        mod, nm = k.split(".")
+        close(getattr(getattr(gen, mod), nm).grad, g["grad__" + k.replace(".", "__")], rtol=1e-4, atol=1e-7)
+    if impl == 1:
+        close(gen(T(g["feats"]), pre_assembled=True), g["out_pre"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+def test_qat_generator_golden(dpd, impl):
+    from oracle import generator as og
+    g = load_golden("g3_qat_gen")
+    params = {k: v for k, v in sd(g, "sd0__").items()}
+    gen = load_gen(dpd, params)
+    gen.kernel_impl = impl
+    gen.train()
+    out1 = gen(T(g["iq"]))
+    close_q(out1, g["out1"])
+    loss = torch.nn.functional.mse_loss(out1, T(g["target"]))
+    loss.backward()
+    close(loss, g["loss"], rtol=1e-5)
+    for k in og.PARAM_KEYS:
+        mod, nm = k.split(".")
+        close(getattr(getattr(gen, mod), nm).grad, g["grad__" + k.replace(".", "__")], rtol=2e-4, atol=1e-7)
+    sd1 = gen.state_dict()
+    for k in gen.ACT_QUANT + gen.WEIGHT_QUANT:
+        close(sd1[k + ".running_scale"], g[f"sd1__{k}__running_scale"], rtol=1e-6, atol=0)
+    close_q(gen(T(g["iq2"])), g["out2"])
+    for k in gen.ACT_QUANT + gen.WEIGHT_QUANT:
+        close(gen.state_dict()[k + ".running_scale"], g[f"sd2__{k}__running_scale"], rtol=1e-6, atol=0)
+    assert set(gen.state_dict().keys()) == {k[len("sd2__"):].replace("__", ".") for k in g.files if k.startswith("sd2__")}
+    gen.eval()
+    close_q(gen(T(g["iq"])), g["out_eval"])
+    for k in gen.ACT_QUANT:
+        close(gen.state_dict()[k + ".running_scale"], g[f"sd3__{k}__running_scale"], rtol=1e-6, atol=0)
+    close_q(gen(T(g["iq"][:1])), g["out_row0"])
+    gen.disable_qat()
+    close(gen(T(g["iq"])), g["out_noq"], rtol=1e-5, atol=1e-6)
+    gen.enable_qat()
+    if impl == 1:
+        close_q(gen(T(g["feats"]), pre_assembled=True), g["out_pre"])
+    qw = gen.get_quantized_weights()
+    for k, v in qw.items():
+        assert np.array_equal(v.cpu().numpy(), g["qw__" + k]), k
+
+
+def test_dynamic_fake_quantize(dpd):
+    from dpd_amd.models import fake_quantize
+    g = load_golden("g3_qat_gen")
+    x = T(g["fq_x"]).requires_grad_(True)
+    y = fake_quantize(x, 16)
+    assert np.array_equal(y.detach().cpu().numpy(), g["fq_tensor"])
+    y.sum().backward()
+    assert torch.equal(x.grad, torch.ones_like(x))
+    assert np.array_equal(fake_quantize(T(g["fq_x"]), 16, per_channel=True, channel_dim=0).cpu().numpy(), g["fq_channel"])
+
+
+def test_init_matches_reference_rng(dpd):
+    """Same seed, same construction order -> same initial parameters as the reference classes."""
+    from dpd_amd.models import TDNNGeneratorQAT
+    g = load_golden("g9_csv_chain")
+    torch.manual_seed(909)
+    gen = TDNNGeneratorQAT()
+    ref = sd(g, "sd__")
+    for k, v in gen.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+
+
+@pytest.mark.parametrize("qat", [False, True])
+@pytest.mark.parametrize("shape", [(3, 21), (5, 133), (2, 1029), (1, 70)])
+def test_mfma_vs_valu_vs_oracle_ragged(dpd, qat, shape):
+    """Ragged row lengths (tiles and chunks partly empty): both kernel families against the oracle."""
+    from oracle import generator as og
+    from dpd_amd.models import TDNNGeneratorQAT
+    B, S = shape
+    torch.manual_seed(7)
+    gen = TDNNGeneratorQAT()
+    with torch.no_grad():
+        for fc in (gen.fc1, gen.fc2, gen.fc3):
+            fc.bias.uniform_(-0.1, 0.1)
+    params = {k: v.clone() for k, v in gen.state_dict().items() if k in og.PARAM_KEYS}
+    gen = gen.to(DEV)
+    gen.qat_enabled = qat
+    iq = ofdm_rows(B, S, seed=B * 1000 + S)
+    tgt = torch.randn(B, S - 5, 2, generator=torch.Generator().manual_seed(3)) * 0.3
+    ref_out, ref_loss, ref_grads = og.gen_mse_grads(iq, tgt, params, qat=qat)
+    for impl in (1, 2):
+        gen.kernel_impl = impl
+        gen.zero_grad()
+        out = gen(iq.to(DEV))
+        (close_q if qat else close)(out, ref_out)
+        loss = torch.nn.functional.mse_loss(out, tgt.to(DEV))
+        loss.backward()
+        for k in og.PARAM_KEYS:
+            mod, nm = k.split(".")
+            close(getattr(getattr(gen, mod), nm).grad, ref_grads[k], rtol=3e-4, atol=2e-7)
+
+
+@pytest.mark.parametrize("qat", [False, True])
+def test_fused_mse_step_matches_autograd_path(dpd, qat):
+    """dpd_gen_mse_step (forward + MSE + backward in one kernel) against the oracle."""
+    from oracle import generator as og
+    from dpd_amd import _lib as L
+    from dpd_amd.models import TDNNGeneratorQAT
+    torch.manual_seed(11)
+    gen = TDNNGeneratorQAT()
+    params = {k: v.clone() for k, v in gen.state_dict().items() if k in og.PARAM_KEYS}
+    B, S = 16, 1029
+    iq = ofdm_rows(B, S, seed=99)
+    tgt = iq[:, 5:, :].contiguous() * 0.9
+    _, ref_loss, ref_grads = og.gen_mse_grads(iq, tgt, params, qat=qat)
+    ref_flat = torch.cat([ref_grads[k].reshape(-1) for k in og.PARAM_KEYS])
+    for impl in (1, 2):
+        dev = torch.device(DEV)
+        p = [params[k].to(dev) for k in og.PARAM_KEYS]
+        wq = torch.empty(L.GEN_NPARAM, device=dev); absmax = torch.zeros(8, device=dev)
+        grads = torch.empty(L.GEN_NPARAM, device=dev); loss = torch.zeros(1, device=dev)
+        x, t = iq.to(dev), tgt.to(dev)
+        st = L.stream()
+        L.call("dpd_gen_prepare_weights", *(L.fptr(w) for w in p), int(qat), L.fptr(wq), L.fptr(absmax), st)
+        if qat:
+            out = torch.empty(B, S - 5, 2, device=dev)
+            for stage in range(4):
+                L.call("dpd_gen_absmax_pass", stage, L.fptr(x), B, S, 0, L.fptr(wq), 0.2, L.fptr(absmax), L.fptr(out), impl, st)
+        _, wsp, wsn = L.workspace(dev)
+        L.call("dpd_gen_mse_step", L.fptr(x), B, S, L.fptr(t), L.fptr(wq), 0.2, int(qat), L.fptr(absmax), L.fptr(grads),
+               L.fptr(loss), wsp, wsn, impl, st)
+        close(loss[0], ref_loss, rtol=1e-5)
+        close(grads, ref_flat, rtol=3e-4, atol=2e-7)
