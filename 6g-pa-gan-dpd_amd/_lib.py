@@ -35,7 +35,7 @@ PROTOTYPES = {
     "dpd_critic_backward": [c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_sz, c_p],
     "dpd_critic_gp": [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p],
     "dpd_spectral_stats": [c_p, c_p, c_l, c_l, c_p, c_p, c_p],
-    "dpd_spectral_backward": [c_p, c_p, c_l, c_l, c_p, c_f, c_p, c_p, c_p],
+    "dpd_spectral_backward": [c_p, c_p, c_l, c_l, c_p, c_p, c_p, c_p],
     "dpd_quantize_fixed": [c_p, c_l, c_f, c_i, c_i, c_i, c_p, c_p],
     "dpd_fake_quantize_dynamic": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p],
     "dpd_q88_infer": [c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
@@ -111,13 +111,13 @@ def stream():
 _workspaces = {}
 
 
-def workspace(device):
-    """One scratch buffer per device, reused by every call on that device (calls on one device and
-    different streams must not overlap)."""
+def workspace(device, n_samples=0):
+    """One scratch buffer per device, grown on demand and reused by every call on that device (calls
+    on one device and different streams must not overlap)."""
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    nbytes = int(lib().dpd_workspace_bytes(int(n_samples)))
     ws = _workspaces.get(key)
-    if ws is None:
-        nbytes = int(lib().dpd_workspace_bytes(0))
+    if ws is None or ws.numel() < nbytes:
         ws = torch.empty(nbytes, dtype=torch.uint8, device=torch.device("cuda", key))
         _workspaces[key] = ws
     return ws, c_p(ws.data_ptr()), c_sz(ws.numel())

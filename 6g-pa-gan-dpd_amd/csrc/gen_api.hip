@@ -36,9 +36,10 @@ int forward_dispatch(const GenProblem &p, int depth, float *out, int impl, hipSt
 }  // namespace
 
 extern "C" size_t dpd_workspace_bytes(int64_t n_samples) {
-    (void)n_samples;
-    // partial-gradient slabs: at most 2048 rows of max(G_SLAB, C_SLAB) floats, plus reduction scratch
-    return (size_t)2048 * C_SLAB * sizeof(float) + (size_t)(1 << 20);
+    // partial-gradient slabs (at most 2048 rows of max(G_SLAB, C_SLAB) floats) plus, for the gradient
+    // penalty, 28 bytes per sample (input gradient, mask bits, row coefficient)
+    if (n_samples < 0) n_samples = 0;
+    return (size_t)2048 * C_SLAB * sizeof(float) + (size_t)(1 << 20) + (size_t)n_samples * 28;
 }
 
 extern "C" int dpd_tap_assembly(const float *iq, int64_t B, int64_t S, float *feat, void *stream) {
@@ -93,8 +94,8 @@ extern "C" int dpd_gen_forward(const float *x, int64_t B, int64_t S, int pre_ass
 static int backward_common(const GenProblem &p, const float *grad_out, const float *target, float *grads, float *loss,
                            float *grad_feat, void *ws, size_t ws_bytes, int impl, hipStream_t st) {
     DPD_REQUIRE(grads, DPD_ERR_INVALID_ARG, "gen_backward: grads is null");
-    DPD_REQUIRE(ws && ws_bytes >= dpd_workspace_bytes(p.N), DPD_ERR_WORKSPACE,
-                "gen_backward: workspace of %zu bytes needed, %zu given", dpd_workspace_bytes(p.N), ws_bytes);
+    DPD_REQUIRE(ws && ws_bytes >= dpd_workspace_bytes(0), DPD_ERR_WORKSPACE,
+                "gen_backward: workspace of %zu bytes needed, %zu given", dpd_workspace_bytes(0), ws_bytes);
     if (p.N == 0) {
         DPD_HIP(hipMemsetAsync(grads, 0, G_NP * sizeof(float), st));
         if (loss) DPD_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
@@ -131,4 +132,19 @@ extern "C" int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const flo
     if (rc) return rc;
     DPD_REQUIRE(target && loss, DPD_ERR_INVALID_ARG, "gen_mse_step: null target or loss");
     return backward_common(p, nullptr, target, grads, loss, nullptr, ws, ws_bytes, impl, as_stream(stream));
+}
+
+// Generator forward with scales already known (QAT: absmax[0..3] filled by the abs-max passes):
+// one pass to the output plus the output quantiser.  Used by the generator -> PA chain.
+int gen_forward_for_chain(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
+                          const float *absmax, float *out, hipStream_t st) {
+    GenProblem p;
+    int rc = make_problem(p, iq, B, S, 0, wq, slope, qat, const_cast<float *>(absmax));
+    if (rc) return rc;
+    if (p.N == 0) return DPD_OK;
+    if (!p.qat) return forward_dispatch(p, 4, out, DPD_IMPL_AUTO, st);
+    // the pass-3 kernel rewrites absmax[3] with the same value it already holds (max is idempotent)
+    rc = forward_dispatch(p, 3, out, DPD_IMPL_AUTO, st);
+    if (rc) return rc;
+    return gen_launch_quantize_output(out, p.N * 2, absmax, st);
 }

@@ -400,6 +400,14 @@ int gen_reduce_slab(const float *slab, int n_partials, float *grads, float *loss
     return DPD_OK;
 }
 
+int gen_reduce_slab_generic(const float *slab, int n_partials, int row_len, int n_out, float *grads, float *extra,
+                            float extra_scale, hipStream_t st) {
+    hipLaunchKernelGGL(k_reduce_slab, dim3((n_out + 1 + 255) / 256), dim3(256), 0, st, slab, n_partials, row_len, n_out,
+                       grads, extra, extra_scale);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
 int gen_launch_prepare(const float *w1, const float *b1, const float *w2, const float *b2, const float *w3,
                        const float *b3, int qat, float *wq, float *absmax, hipStream_t st) {
     hipLaunchKernelGGL(k_prepare_weights, dim3(1), dim3(64), 0, st, w1, b1, w2, b2, w3, b3, qat, wq, absmax);

@@ -1,0 +1,130 @@
+// Memory-polynomial PA twin (reference models/pa_digital_twin.py:125-170):
+//   y[n] = sum_k sum_m h[k,m] * x[n+M-1-m] * |x[n+M-1-m]|^(2k),  k = 0..K-1 (orders 1,3,5,..), m = 0..M-1
+// evaluated per tap as x * P_m(|x|^2) with P_m a complex polynomial (Horner).  Forward: one lane per
+// output sample.  Backward: one lane per INPUT sample gathers its <= M contributions, so there
+// are no atomics; d|x|/dx at 0 is 0 because every k >= 1 term carries a factor x.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXK = 8, MAXM = 16;
+
+struct Coefs {
+    float re[MAXK * MAXM];
+    float im[MAXK * MAXM];
+};
+
+DEV void load_coefs(float *sre, float *sim, const float *__restrict__ cre, const float *__restrict__ cim, int K, int M) {
+    for (int i = threadIdx.x; i < K * M; i += blockDim.x) {
+        sre[i] = cre[i];
+        sim[i] = cim[i];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_pa_fwd(const float2 *__restrict__ x, int64_t S, int64_t OL, int64_t N,
+                                                const float *__restrict__ cre, const float *__restrict__ cim, int K,
+                                                int M, float2 *__restrict__ y) {
+    __shared__ float sre[MAXK * MAXM], sim[MAXK * MAXM];
+    load_coefs(sre, sim, cre, cim, K, M);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / OL, n = i - b * OL;
+        const float2 *row = x + b * S + n;
+        float yr = 0.f, yi = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const float2 v = row[M - 1 - m];
+            const float p = v.x * v.x + v.y * v.y;
+            float pr = sre[(K - 1) * M + m], pi = sim[(K - 1) * M + m];
+            for (int k = K - 2; k >= 0; --k) {
+                pr = __builtin_fmaf(pr, p, sre[k * M + m]);
+                pi = __builtin_fmaf(pi, p, sim[k * M + m]);
+            }
+            yr += v.x * pr - v.y * pi;
+            yi += v.x * pi + v.y * pr;
+        }
+        y[i] = make_float2(yr, yi);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pa_bwd(const float2 *__restrict__ x, int64_t S, int64_t OL, int64_t NX,
+                                                const float *__restrict__ cre, const float *__restrict__ cim, int K,
+                                                int M, const float2 *__restrict__ gy, float2 *__restrict__ gx) {
+    __shared__ float sre[MAXK * MAXM], sim[MAXK * MAXM];
+    load_coefs(sre, sim, cre, cim, K, M);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < NX; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / S, t = i - b * S;
+        const float2 v = x[i];
+        const float p = v.x * v.x + v.y * v.y;
+        float gr = 0.f, gi = 0.f;
+        for (int m = 0; m < M; ++m) {
+            const int64_t n = t - (M - 1) + m;   // output that reads x[t] through tap m
+            if (n < 0 || n >= OL) continue;
+            const float2 c = gy[b * OL + n];
+            // P_m(p) and P_m'(p)
+            float pr = sre[(K - 1) * M + m], pi = sim[(K - 1) * M + m], dr = 0.f, di = 0.f;
+            for (int k = K - 2; k >= 0; --k) {
+                dr = __builtin_fmaf(dr, p, pr);
+                di = __builtin_fmaf(di, p, pi);
+                pr = __builtin_fmaf(pr, p, sre[k * M + m]);
+                pi = __builtin_fmaf(pi, p, sim[k * M + m]);
+            }
+            // f = x * P(p): fr = xr Pr - xi Pi, fi = xr Pi + xi Pr
+            const float ar = v.x * dr - v.y * di;   // d fr / d p
+            const float ai = v.x * di + v.y * dr;   // d fi / d p
+            const float s = 2.f * (c.x * ar + c.y * ai);
+            gr += c.x * pr + c.y * pi + s * v.x;
+            gi += -c.x * pi + c.y * pr + s * v.y;
+        }
+        gx[i] = make_float2(gr, gi);
+    }
+}
+
+}  // namespace
+
+static int pa_check(const float *x, int64_t B, int64_t S, const float *cre, const float *cim, int K, int M) {
+    DPD_REQUIRE(x && cre && cim, DPD_ERR_INVALID_ARG, "pa: null pointer");
+    DPD_REQUIRE(K >= 1 && K <= MAXK && M >= 1 && M <= MAXM, DPD_ERR_INVALID_ARG, "pa: K=%d (1..8) or M=%d (1..16) unsupported", K, M);
+    DPD_REQUIRE(B >= 0, DPD_ERR_INVALID_ARG, "pa: negative batch");
+    DPD_REQUIRE(S >= M, DPD_ERR_SHAPE, "Sequence length %lld must be >= memory depth %d", (long long)S, M);
+    return DPD_OK;
+}
+
+extern "C" int dpd_pa_forward(const float *x, int64_t B, int64_t S, const float *coef_re, const float *coef_im, int K,
+                              int M, float *y, void *stream) {
+    int rc = pa_check(x, B, S, coef_re, coef_im, K, M);
+    if (rc) return rc;
+    DPD_REQUIRE(y, DPD_ERR_INVALID_ARG, "pa_forward: y is null");
+    const int64_t OL = S - M + 1, N = B * OL;
+    if (N == 0) return DPD_OK;
+    hipLaunchKernelGGL(k_pa_fwd, dim3(grid_for(N, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(x), S, OL, N, coef_re, coef_im, K, M,
+                       reinterpret_cast<float2 *>(y));
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+extern "C" int dpd_pa_backward(const float *x, int64_t B, int64_t S, const float *coef_re, const float *coef_im, int K,
+                               int M, const float *gy, float *gx, void *stream) {
+    int rc = pa_check(x, B, S, coef_re, coef_im, K, M);
+    if (rc) return rc;
+    DPD_REQUIRE(gy && gx, DPD_ERR_INVALID_ARG, "pa_backward: null gradient pointer");
+    const int64_t OL = S - M + 1, NX = B * S;
+    if (NX == 0) return DPD_OK;
+    hipLaunchKernelGGL(k_pa_bwd, dim3(grid_for(NX, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<const float2 *>(x), S, OL, NX, coef_re, coef_im, K, M,
+                       reinterpret_cast<const float2 *>(gy), reinterpret_cast<float2 *>(gx));
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+int gen_forward_for_chain(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
+                          const float *absmax, float *out, hipStream_t st);
+
+extern "C" int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
+                                  const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
+                                  float *dpd_out, float *y, void *stream) {
+    DPD_REQUIRE(dpd_out && y, DPD_ERR_INVALID_ARG, "gen_pa_forward: dpd_out and y are required");
+    int rc = gen_forward_for_chain(iq, B, S, wq, slope, qat, absmax, dpd_out, as_stream(stream));
+    if (rc) return rc;
+    return dpd_pa_forward(dpd_out, B, S - DPD_GEN_MEMORY, coef_re, coef_im, K, M, y, stream);
+}

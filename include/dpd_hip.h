@@ -47,7 +47,8 @@ extern "C" {
 const char *dpd_last_error(void);
 int dpd_version(void);
 
-/* Scratch size in bytes that the ws-taking entry points need for a problem of n_samples. */
+/* Scratch size in bytes for the ws-taking entry points: dpd_workspace_bytes(0) suffices for every
+ * call except dpd_critic_gp, which needs dpd_workspace_bytes(B * L). */
 size_t dpd_workspace_bytes(int64_t n_samples);
 
 /* ---------------------------------------------------------------- generator ------------- */
@@ -112,8 +113,9 @@ int dpd_pa_forward(const float *x, int64_t B, int64_t S, const float *coef_re, c
 int dpd_pa_backward(const float *x, int64_t B, int64_t S, const float *coef_re, const float *coef_im,
                     int K, int M, const float *gy, float *gx, void *stream);
 
-/* Fused chain iq -> generator -> PA twin (the validation chain of demo/video_demo.py:221-248):
- * y [B, S-5-M+1, 2]; dpd_out (optional) also receives the generator output [B,S-5,2]. */
+/* Chain iq -> generator -> PA twin (the validation chain of demo/video_demo.py:221-248) on one
+ * stream: dpd_out [B,S-5,2] receives the generator output, y [B, S-5-M+1, 2] the PA output.
+ * With qat != 0 absmax[0..3] must already hold the four scales (dpd_gen_absmax_pass 0..3). */
 int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
                        const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
                        float *dpd_out, float *y, void *stream);
@@ -143,18 +145,20 @@ int dpd_critic_gp(const float *real, const float *fake, const float *cond, const
 /* ---------------------------------------------------------------- spectral loss --------- */
 
 /* Per-row statistics behind compute_evm / compute_acpr / compute_nmse / SpectralLoss
- * (utils/spectral_loss.py:24-167, :209-257) for pred, target [B,L,2]; L a power of two, 8..4096.
+ * (utils/spectral_loss.py:24-167, :209-257) for pred, target [B,L,2]; L a power of two, 2..4096.
  * band [3,L] uint8 masks (main, lower, upper) as produced from fftfreq (:103-110).
  * stats [B,8]: sum|p-t|, sum|p-t|^2, sum|t|^2, P_main, P_lower, P_upper (of pred, |X|^2/L), 0, 0.
- * target may be NULL (ACPR only): the first three entries are then 0. */
+ * target may be NULL (ACPR only): the first three entries are then 0.  band may be NULL (EVM / NMSE /
+ * L1 only): no transform is done, any L >= 1 is accepted and the band powers are 0. */
 int dpd_spectral_stats(const float *pred, const float *target, int64_t B, int64_t L,
                        const uint8_t *band, float *stats, void *stream);
 
-/* Backward: dpred [B,L,2] = c_l1 * sign(p-t) + rowc[b,0] * (p-t) + (2/L) * IDFT_unnormalised(
- * (rowc[b,1]*main + rowc[b,2]*lower + rowc[b,3]*upper) * X) with X = FFT(pred row b);
- * rowc [B,4] holds the per-row chain-rule coefficients. */
+/* Backward for gstats [B,8] = d loss / d stats (entries 2, 6, 7 ignored):
+ * dpred [B,L,2] = gstats[b,0] * sign(p-t) + 2 * gstats[b,1] * (p-t)
+ *               + (2/L) * IDFT_unnormalised((gstats[b,3]*main + gstats[b,4]*lower + gstats[b,5]*upper) * X),
+ * X = FFT(pred row b).  target may be NULL (the first two terms are then dropped). */
 int dpd_spectral_backward(const float *pred, const float *target, int64_t B, int64_t L,
-                          const uint8_t *band, float c_l1, const float *rowc, float *dpred, void *stream);
+                          const uint8_t *band, const float *gstats, float *dpred, void *stream);
 
 /* ---------------------------------------------------------------- fixed point ----------- */
 

@@ -1,0 +1,191 @@
+"""GPU parity of the spectral metrics/loss, the fixed-point primitives and the Q8.8 integer inference.
+Tolerances: dB metrics within 0.1 dB (asserted far tighter), loss scalars rel 1e-5, loss gradients
+rel 1e-3 of their scale; fixed-point and Q8.8 results bit-exact."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+
+from gpu_util import DEV, T, close, load_golden, ofdm_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def test_spectral_golden():
+    from dpd_amd.utils import (ACPRLoss, EVMLoss, SpectralLoss, compute_acpr, compute_evm, compute_nmse)
+    g = load_golden("g8_spectral")
+    sl = SpectralLoss()
+    for n in (256, 1024):
+        pred = T(g[f"L{n}_pred"]).requires_grad_(True)
+        tgt = T(g[f"L{n}_target"])
+        total, comps = sl(pred, tgt, return_components=True)
+        close(total, g[f"L{n}_total"], rtol=1e-5)
+        for k in ("l1", "evm", "acpr"):
+            close(comps[k], g[f"L{n}_{k}"], rtol=1e-5, atol=1e-7)
+        total.backward()
+        ref = g[f"L{n}_dpred"]
+        close(pred.grad, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+        p = pred.detach()
+        assert np.abs(compute_evm(p, tgt).cpu().numpy() - g[f"L{n}_evm_db"]).max() < 1e-3
+        close(compute_evm(p, tgt, return_db=False), g[f"L{n}_evm_lin"], rtol=1e-5)
+        assert np.abs(compute_nmse(p, tgt).cpu().numpy() - g[f"L{n}_nmse_db"]).max() < 1e-3
+        close(compute_nmse(p, tgt, return_db=False), g[f"L{n}_nmse_lin"], rtol=1e-5)
+        lo, up = compute_acpr(p)
+        assert np.abs(lo.cpu().numpy() - g[f"L{n}_acpr_lo_db"]).max() < 1e-2   # bar: 0.1 dB
+        assert np.abs(up.cpu().numpy() - g[f"L{n}_acpr_up_db"]).max() < 1e-2
+        lo, up = compute_acpr(p, return_db=False)
+        close(lo, g[f"L{n}_acpr_lo_lin"], rtol=2e-4); close(up, g[f"L{n}_acpr_up_lin"], rtol=2e-4)
+        m = sl.compute_metrics(p, tgt)
+        for k, v in m.items():
+            ref = float(g[f"L{n}_metric__{k}"])
+            assert abs(v - ref) < (1e-2 if k.endswith("_db") else 1e-6), (k, v, ref)
+        # complex [B, L] input form
+        pc = torch.complex(p[..., 0], p[..., 1])
+        tc = torch.complex(tgt[..., 0], tgt[..., 1])
+        assert np.abs(compute_evm(pc, tc).cpu().numpy() - g[f"L{n}_evm_db"]).max() < 1e-3
+    tgt = T(g["L256_target"])
+    pp = T(g["clamp_pred"]).requires_grad_(True)
+    total, comps = sl(pp, tgt, return_components=True)
+    close(total, g["clamp_total"], rtol=1e-5)
+    close(comps["evm"], g["clamp_evm"], rtol=1e-5, atol=1e-7)
+    total.backward()
+    close(pp.grad, g["clamp_dpred"], rtol=1e-3, atol=1e-3 * np.abs(g["clamp_dpred"]).max())
+    p256 = T(g["L256_pred"]).requires_grad_(True)
+    el = EVMLoss()(p256, tgt)
+    close(el, g["evmloss"], rtol=1e-5)
+    el.backward()
+    close(p256.grad, g["evmloss_d"], rtol=1e-3, atol=1e-3 * np.abs(g["evmloss_d"]).max())
+    p256 = T(g["L256_pred"]).requires_grad_(True)
+    al = ACPRLoss()(p256)
+    close(al, g["acprloss"], rtol=1e-4)
+    al.backward()
+    close(p256.grad, g["acprloss_d"], rtol=2e-3, atol=2e-3 * np.abs(g["acprloss_d"]).max())
+
+
+def test_band_masks_match_reference():
+    from dpd_amd.utils.spectral_loss import band_masks
+    g = load_golden("g8_spectral")
+    for n in (256, 1024, 4096, 100):
+        assert np.array_equal(band_masks(n, 200e6, 100e6, 100e6, DEV).cpu().numpy(), g[f"mask{n}"])
+
+
+@pytest.mark.parametrize("n", [2, 8, 64, 512, 4096])
+def test_spectral_vs_oracle_lengths(n):
+    """Every supported FFT length, forward statistics and gradient, against the torch-CPU oracle."""
+    from oracle import spectral as osp
+    from dpd_amd.utils import SpectralLoss
+    gen = torch.Generator().manual_seed(n)
+    tgt = torch.randn(3, n, 2, generator=gen) * 0.3
+    pred = (tgt + 0.05 * torch.randn(3, n, 2, generator=gen)).requires_grad_(True)
+    ref, comps = osp.spectral_loss(pred, tgt)
+    (rg,) = torch.autograd.grad(ref, pred)
+    p = pred.detach().to(DEV).requires_grad_(True)
+    total = SpectralLoss()(p, tgt.to(DEV))
+    close(total, ref.detach(), rtol=2e-5)
+    total.backward()
+    close(p.grad, rg, rtol=1e-3, atol=1e-3 * float(rg.abs().max()))
+
+
+def test_spectral_unsupported_length_raises():
+    from dpd_amd.utils import compute_acpr, compute_evm
+    x = torch.randn(2, 100, 2, device=DEV)
+    with pytest.raises(NotImplementedError):
+        compute_acpr(x)
+    compute_evm(x, x * 0.9)          # no transform needed: any length
+
+
+def test_fixed_point_primitives_bit_exact():
+    from dpd_amd.utils import (QuantizationConfig, QuantizedLinear, dequantize_from_fixed_point, export_weights_binary,
+                               fake_quantize, generate_leaky_relu_params, generate_tanh_lut, load_weights_binary,
+                               quantize_to_fixed_point)
+    g = load_golden("g4_fixed_point")
+    cfg = QuantizationConfig()
+    eq = lambda a, b: np.array_equal(a.cpu().numpy(), b)
+    assert eq(quantize_to_fixed_point(T(g["edge15"]), cfg.weight_scale, 16), g["q15"])
+    assert eq(quantize_to_fixed_point(T(g["edge8"]), cfg.activation_scale, 16), g["q8"])
+    assert eq(quantize_to_fixed_point(T(g["rnd"]), cfg.activation_scale, 16), g["q8r"])
+    assert eq(quantize_to_fixed_point(T(g["edge8"]), 16.0, 8, signed=False), g["qu8"])
+    assert eq(fake_quantize(T(g["edge15"]), cfg.weight_scale, 16), g["fq15"])
+    assert eq(fake_quantize(T(g["rnd"]), cfg.activation_scale, 16), g["fq8r"])
+    assert eq(dequantize_from_fixed_point(T(g["q8"]), cfg.activation_scale), g["dq8"])
+    assert cfg.weight_range == (-32768, 32767) and cfg.activation_range == (-32768, 32767) and cfg.io_scale == 32768
+    ql = QuantizedLinear(30, 32, cfg)
+    with torch.no_grad():
+        ql.weight.copy_(torch.from_numpy(g["ql_weight"])); ql.bias.copy_(torch.from_numpy(g["ql_bias"]))
+    ql = ql.to(DEV)
+    x = T(g["ql_x"]).requires_grad_(True)
+    y = ql(x)
+    # the matmul runs in a library GEMM with its own summation order: allow one Q8.8 step on a few entries
+    d = np.abs(y.detach().cpu().numpy() - g["ql_y"])
+    assert d.max() <= 1 / 256 + 1e-7 and (d == 0).mean() > 0.99
+    y.backward(T(g["ql_gy"]))
+    close(x.grad, g["ql_gx"], rtol=1e-4, atol=1e-6); close(ql.weight.grad, g["ql_gw"], rtol=1e-4, atol=1e-6)
+    close(ql.bias.grad, g["ql_gb"], rtol=1e-5, atol=1e-6)
+    qw = ql.get_quantized_weights()
+    assert eq(qw["weight"], g["ql_w_int"]) and eq(qw["bias"], g["ql_b_int"])
+    assert np.array_equal(generate_tanh_lut().numpy(), g["tanh_lut"])
+    assert np.array_equal(generate_tanh_lut(num_entries=16).numpy(), g["tanh_lut16"])
+    lp = generate_leaky_relu_params(0.2)
+    assert lp["shift_amount"] == int(g["lrelu_shift"]) and lp["actual_slope"] == float(g["lrelu_slope"])
+    wd = {"fc1_weight": torch.from_numpy(g["bin_fc1_weight"]), "fc1_bias": torch.from_numpy(g["bin_fc1_bias"])}
+    with tempfile.TemporaryDirectory() as d:
+        for en, ref in (("little", g["bin_blob_le"]), ("big", g["bin_blob_be"])):
+            p = os.path.join(d, en + ".bin")
+            export_weights_binary(wd, p, endianness=en)
+            assert open(p, "rb").read() == ref.tobytes()
+            back = load_weights_binary(p, endianness=en)
+            assert all(torch.equal(back[k], wd[k]) for k in wd)
+        open(os.path.join(d, "bad.bin"), "wb").write(b"\x00" * 16)
+        with pytest.raises(ValueError):
+            load_weights_binary(os.path.join(d, "bad.bin"))
+
+
+@pytest.mark.parametrize("acc64", [False, True])
+def test_q88_golden_bit_exact(acc64):
+    from dpd_amd.utils import Q88Inference
+    g = load_golden("g11_q88")
+    w = {k: T(g[k]) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "lut")}
+    eng = Q88Inference(w, force_acc64=acc64)
+    assert eng.acc64 == acc64          # these weights are provably safe for 32-bit accumulation
+    out = eng(T(g["iq_i16"]))
+    assert np.array_equal(out.cpu().numpy()[0], g["out_i16"])
+    with pytest.raises(ValueError):
+        eng(torch.zeros(1, 5, 2, dtype=torch.int16, device=DEV))
+
+
+def test_q88_random_rows_and_extremes_vs_oracle():
+    """Random full-range int16 IQ (exercises saturation), perfect-square envelopes (exact ties), ragged
+    row length, and weights large enough that the 32-bit proof fails (64-bit path is selected)."""
+    from oracle import q88 as oq
+    from dpd_amd.utils import Q88Inference
+    g = load_golden("g11_q88")
+    rng = np.random.default_rng(5)
+    iq = rng.integers(-32768, 32768, size=(3, 203, 2), dtype=np.int64).astype(np.int16)
+    iq[0, :40, 0] = (np.arange(40) * 192 + 64).astype(np.int16); iq[0, :40, 1] = 0     # sqrt(s)/128 on .5 ties
+    iq[1, 7] = (32767, -32768); iq[1, 8] = (-32768, -32768); iq[2, 9] = (1024, 1024)
+    base = [g[k] for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
+    big = [rng.integers(-32768, 32768, size=a.shape, dtype=np.int64).astype(np.int16) for a in base]
+    for ws, expect64 in ((base, False), (big, True)):
+        w = {k: T(a) for k, a in zip(("w1", "b1", "w2", "b2", "w3", "b3"), ws)}
+        w["lut"] = T(g["lut"])
+        eng = Q88Inference(w)
+        assert eng.acc64 == expect64
+        out = eng(T(iq)).cpu().numpy()
+        ref = oq.infer_rows(iq, *ws, g["lut"])
+        assert np.array_equal(out, ref)
+
+
+def test_q88_export_from_generator():
+    from dpd_amd.models import TDNNGeneratorQAT
+    from dpd_amd.utils import Q88Inference, export_q88_weights
+    from oracle import q88 as oq
+    torch.manual_seed(3)
+    gen = TDNNGeneratorQAT().to(DEV)
+    w = export_q88_weights(gen)
+    assert w["w1"].dtype == torch.int16 and tuple(w["w1"].shape) == (32, 30) and tuple(w["lut"].shape) == (256,)
+    iq = (ofdm_rows(2, 133, seed=4) * 32768).round().clamp(-32768, 32767).to(torch.int16)
+    out = Q88Inference(w)(iq.to(DEV)).cpu().numpy()
+    ref = oq.infer_rows(iq.numpy(), *(w[k].cpu().numpy() for k in ("w1", "b1", "w2", "b2", "w3", "b3", "lut")))
+    assert np.array_equal(out, ref)
