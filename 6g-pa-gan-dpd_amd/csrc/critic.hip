@@ -122,6 +122,7 @@ DEV void panel_accumulate(const float *lp, const float *rp, int tid, float (&acc
     }
 }
 
+template <bool WGRAD>
 __global__ __launch_bounds__(TPB) void k_critic_bwd(const float2 *__restrict__ x, const float2 *__restrict__ cond,
                                                     int64_t N, const float *__restrict__ wb, float slope,
                                                     const float *__restrict__ gscore, float gconst,
@@ -191,10 +192,13 @@ __global__ __launch_bounds__(TPB) void k_critic_bwd(const float2 *__restrict__ x
             for (int k = 0; k < NL; ++k) l[k] = 0.f;
             for (int k = 0; k < NR; ++k) r[k] = 0.f;
         }
-        __syncthreads();
-        panel_accumulate<LP, RP>(lp, rp, tid, acc, [](int e, int &lc, int &rc) { entry_cols_bwd(e, lc, rc); });
-        __syncthreads();
+        if (WGRAD) {
+            __syncthreads();
+            panel_accumulate<LP, RP>(lp, rp, tid, acc, [](int e, int &lc, int &rc) { entry_cols_bwd(e, lc, rc); });
+            __syncthreads();
+        }
     }
+    if (!WGRAD) return;
     float *row = slab + (int64_t)blockIdx.x * C_SLAB;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) {
@@ -402,11 +406,11 @@ extern "C" int dpd_critic_forward(const float *x, const float *cond, int64_t N, 
 extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope,
                                    const float *gscore, float gconst, float *grads, float *gx, void *ws,
                                    size_t ws_bytes, void *stream) {
-    DPD_REQUIRE(x && cond && wb && grads, DPD_ERR_INVALID_ARG, "critic_backward: null pointer");
-    DPD_REQUIRE(ws && ws_bytes >= dpd_workspace_bytes(0), DPD_ERR_WORKSPACE, "critic_backward: workspace too small");
+    DPD_REQUIRE(x && cond && wb && (grads || gx), DPD_ERR_INVALID_ARG, "critic_backward: null pointer");
+    DPD_REQUIRE(!grads || (ws && ws_bytes >= dpd_workspace_bytes(0)), DPD_ERR_WORKSPACE, "critic_backward: workspace too small");
     hipStream_t st = as_stream(stream);
     if (N <= 0) {
-        DPD_HIP(hipMemsetAsync(grads, 0, C_NP * sizeof(float), st));
+        if (grads) DPD_HIP(hipMemsetAsync(grads, 0, C_NP * sizeof(float), st));
         return DPD_OK;
     }
     const int grid = grid_for(N, TPB, 1024);
@@ -414,11 +418,20 @@ extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N,
     constexpr size_t lds_bytes = (size_t)(C_NP + 3 + TPB * LP + TPB * RP) * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
-        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_critic_bwd),
+        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_critic_bwd<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_critic_bwd<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         attr_set = true;
     }
-    hipLaunchKernelGGL(k_critic_bwd, dim3(grid), dim3(TPB), lds_bytes, st, reinterpret_cast<const float2 *>(x),
+    if (!grads) {   // input gradient only (generator update): no panel reduction, no slab
+        hipLaunchKernelGGL(k_critic_bwd<false>, dim3(grid_for(N, TPB, 4096)), dim3(TPB), lds_bytes, st,
+                           reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(cond), N, wb, slope,
+                           gscore, gconst, reinterpret_cast<float2 *>(gx), slab);
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
+    hipLaunchKernelGGL(k_critic_bwd<true>, dim3(grid), dim3(TPB), lds_bytes, st, reinterpret_cast<const float2 *>(x),
                        reinterpret_cast<const float2 *>(cond), N, wb, slope, gscore, gconst,
                        reinterpret_cast<float2 *>(gx), slab);
     DPD_LAUNCH_CHECK();

@@ -79,9 +79,12 @@ class _CriticFn(torch.autograd.Function):
     def backward(ctx, gscore):
         xc, cc, wbc = ctx.saved_tensors
         N = xc.shape[0]
-        grads = torch.empty(L.CRITIC_NPARAM, dtype=torch.float32, device=xc.device)
+        need_w = ctx.needs_input_grad[2]
+        if not (need_w or ctx.need_x):
+            return None, None, None, None
+        grads = torch.empty(L.CRITIC_NPARAM, dtype=torch.float32, device=xc.device) if need_w else None
         gx = torch.empty_like(xc) if ctx.need_x else None
-        _, wsp, wsn = L.workspace(xc.device, N)
+        _, wsp, wsn = L.workspace(xc.device)
         L.call("dpd_critic_backward", L.fptr(xc), L.fptr(cc), N, L.fptr(wbc), ctx.slope, L.fptr(L.as_f32(gscore)), 0.0,
                L.fptr(grads), L.fptr(gx), wsp, wsn, L.stream())
         return gx, None, grads, None

@@ -1,0 +1,85 @@
+"""Single-node data parallelism for the DPD training steps: one process per GPU, torch.distributed
+over RCCL (backend "nccl" on ROCm) or gloo in CPU tests.
+
+The hot path shards by IQ row: every sample's 5 taps of history live in its own row, the row FFT
+is per row, so ranks never exchange samples.  What crosses the xGMI links per optimiser step is
+tiny (generator 1,554 + critic 2,945 fp32 gradients, a handful of scalars), i.e. latency-bound:
+the design minimises the NUMBER of collectives (one flat buffer per backward) rather than bytes.
+
+Exact-global semantics (results equal to one process on the concatenated batch):
+  * QAT activation scales are global abs-max reductions  -> all_reduce(MAX) between passes;
+  * losses that are non-linear in batch means (clamped EVM / ACPR terms) are formed from
+    all-reduced per-row sums via GlobalSum, whose backward is the identity;
+  * every loss term is then a function of global sums, so gradients are all-reduced with SUM.
+"""
+from typing import Iterable, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class _GlobalSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, group):
+        y = x.clone()
+        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        # every rank evaluates the same downstream loss on the global sum; the contribution of this
+        # rank's addend to it has derivative 1.  (Gradients are summed over ranks afterwards.)
+        return g, None
+
+
+class DataParallel:
+    """Thin wrapper over a process group; with world == 1 every method is a no-op."""
+
+    def __init__(self, group=None):
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.group = group
+        self.world = dist.get_world_size(group) if self.enabled else 1
+        self.rank = dist.get_rank(group) if self.enabled else 0
+
+    # ---- sharding -------------------------------------------------------------------------
+    def shard_rows(self, n_rows: int):
+        """Contiguous block of rows for this rank (the last ranks get one row less when uneven)."""
+        base, rem = divmod(n_rows, self.world)
+        start = self.rank * base + min(self.rank, rem)
+        return start, start + base + (1 if self.rank < rem else 0)
+
+    # ---- collectives ----------------------------------------------------------------------
+    def max_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return t
+
+    def sum_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def mean_(self, t: torch.Tensor) -> torch.Tensor:
+        if self.enabled:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            t.div_(self.world)
+        return t
+
+    def global_sum(self, x: torch.Tensor) -> torch.Tensor:
+        """Differentiable all-reduce(SUM) (see module docstring)."""
+        return _GlobalSumFn.apply(x, self.group) if self.enabled else x
+
+    def sum_grads_(self, params: Iterable[torch.nn.Parameter]) -> None:
+        """One all-reduce(SUM) over the gradients of `params`, packed into a flat buffer."""
+        if not self.enabled:
+            return
+        grads = [p.grad for p in params if p.grad is not None]
+        if not grads:
+            return
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        off = 0
+        for g in grads:
+            n = g.numel()
+            g.copy_(flat[off:off + n].view_as(g))
+            off += n

@@ -75,3 +75,80 @@ class Stage1Step:
                 getattr(gen, name).observe(self.absmax[i])
         self.opt.step()
         return loss
+
+
+class Stage2Step:
+    """CWGAN-GP step: n_critic critic updates (Wasserstein + gradient penalty), then one generator
+    update on w_adv * adversarial + w_l1 * L1 + SpectralLoss (the combination of train.py:336-340).
+
+    `alphas` (optional, [n_critic, B, 1]) fixes the interpolation coefficients; by default they are
+    drawn on the device.  With a DataParallel context every loss term is formed from global sums
+    and gradients are all-reduced once per backward (see parallel.py).
+    """
+
+    def __init__(self, generator, discriminator, g_opt=None, d_opt=None, n_critic: int = 5, gp_weight: float = 10.0,
+                 w_adv: float = 1.0, w_l1: float = 50.0, spectral_loss=None, dp=None):
+        from .models.discriminator import WassersteinLoss
+        from .utils.spectral_loss import SpectralLoss
+        from .parallel import DataParallel
+        self.gen, self.disc = generator, discriminator
+        self.g_opt = g_opt or torch.optim.Adam(generator.parameters(), **ADAM)
+        self.d_opt = d_opt or torch.optim.Adam(discriminator.parameters(), **ADAM)
+        self.n_critic, self.w_adv, self.w_l1 = n_critic, w_adv, w_l1
+        self.wl = WassersteinLoss(gp_weight)
+        self.sl = spectral_loss or SpectralLoss()
+        self.dp = dp or DataParallel()
+        if self.dp.enabled:
+            generator.absmax_sync = self.dp.max_
+
+    def _critic_loss(self, target, fake, cond, alpha):
+        dev = target.device
+        total, info = self.wl.discriminator_loss(self.disc, target, fake, cond, dev, alpha=alpha, sync_info=False)
+        # means over the local shard; with equal shards the global mean is their average
+        return total / self.dp.world, info
+
+    def _generator_loss(self, fake, target, cond):
+        from .utils.spectral_loss import _loss_terms
+        dp, sl = self.dp, self.sl
+        g_adv, _ = self.wl.generator_loss(self.disc, fake, cond, sync_info=False)
+        l1, evm_db, lo_db, up_db, _ = _loss_terms(fake, target, sl.sample_rate, sl.channel_bw, sl.adjacent_offset)
+        B = fake.shape[0] * dp.world
+        sums = dp.global_sum(torch.stack([l1 / dp.world, evm_db.sum() / B, lo_db.sum() / B, up_db.sum() / B,
+                                          g_adv / dp.world]))
+        l1_g, evm_mean, lo_mean, up_mean, adv_g = sums.unbind(0)
+        evm_loss = torch.clamp((evm_mean + 40) / 40, 0, 2)
+        acpr_loss = torch.clamp((torch.max(lo_mean, up_mean) + 50) / 50, 0, 2)
+        spectral = sl.l1_weight * l1_g + sl.evm_weight * evm_loss + sl.acpr_weight * acpr_loss
+        total = self.w_adv * adv_g + self.w_l1 * l1_g + spectral
+        return total, dict(g_total=total.detach(), g_adv=adv_g.detach(), recon=l1_g.detach(), spectral=spectral.detach(),
+                           evm=evm_loss.detach(), acpr=acpr_loss.detach())
+
+    def __call__(self, iq: torch.Tensor, target: torch.Tensor, cond: torch.Tensor, alphas=None) -> Dict[str, torch.Tensor]:
+        gen, disc, dp = self.gen, self.disc, self.dp
+        info = {}
+        d_params = list(disc.parameters())
+        for it in range(self.n_critic):
+            self.d_opt.zero_grad(set_to_none=True)
+            with torch.no_grad():
+                fake = gen(iq)
+            alpha = alphas[it] if alphas is not None else None
+            d_total, d_info = self._critic_loss(target, fake, cond, alpha)
+            d_total.backward()
+            dp.sum_grads_(d_params)
+            self.d_opt.step()
+            info[f"d_total_{it}"] = dp.sum_(d_total.detach().clone())
+        self.g_opt.zero_grad(set_to_none=True)
+        # the critic is frozen for the generator update: its parameter gradients would be discarded
+        for p in d_params:
+            p.requires_grad_(False)
+        try:
+            fake = gen(iq)
+            g_total, g_info = self._generator_loss(fake, target, cond)
+            g_total.backward()
+        finally:
+            for p in d_params:
+                p.requires_grad_(True)
+        dp.sum_grads_(gen.parameters())
+        self.g_opt.step()
+        info.update(g_info)
+        return info

@@ -129,7 +129,8 @@ int dpd_critic_forward(const float *x, const float *cond, int64_t N, const float
                        float *score, float *score_sum, void *stream);
 
 /* Backward for an upstream gscore[N] (or, if gscore is NULL, the constant gconst for every row):
- * grads[2945] w.r.t. wb and optionally gx [N,2] w.r.t. x. */
+ * grads[2945] w.r.t. wb and/or gx [N,2] w.r.t. x (either may be NULL, not both; ws is only needed
+ * when grads is requested). */
 int dpd_critic_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope,
                         const float *gscore, float gconst, float *grads, float *gx,
                         void *ws, size_t ws_bytes, void *stream);
