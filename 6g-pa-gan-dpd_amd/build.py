@@ -9,7 +9,9 @@ LIB = os.path.join(HERE, "libdpd_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -ffp-contract=off: the reference computes I*I + Q*Q and friends with separate roundings; fused
 # multiply-adds are written explicitly where they are wanted.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC",
+# -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs; the kernels consume them on the VALU right
+# away, and the AGPR form costs one v_accvgpr_read/write per value.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-mllvm", "-amdgpu-mfma-vgpr-form=1",
          "-Wno-unused-result", "-I", os.path.join(os.path.dirname(HERE), "include")]
 
 

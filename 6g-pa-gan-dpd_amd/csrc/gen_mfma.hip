@@ -28,14 +28,16 @@ constexpr int WAVES = 4;
 constexpr int CHUNK = 64;           // samples per wave iteration
 constexpr int SER_STRIDE = 71;      // words between series (71 = 7 mod 32: bank-disjoint operand reads)
 constexpr int SER_BASE0 = 5;
-constexpr int ZERO_W = 360;         // a word that always holds 0 (slots 30, 31)
-constexpr int SER_WORDS = 368;
+constexpr int ZERO_W = 360;         // 64 words that always hold 0: operand of the padding slots 30, 31
+                                    // (their reads add the same tile / sample offsets as real slots)
+constexpr int SER_WORDS = 424;
 constexpr int P32 = 48;             // row pitch of the 32-column transposition tiles (16 mod 32)
 constexpr int P16 = 16;
 constexpr int GZ1_W = SER_WORDS;                 // 16 x 48
 constexpr int H1_W = GZ1_W + 16 * P32;           // 16 x 48
 constexpr int GZ2_W = H1_W + 16 * P32;           // 16 x 16
 constexpr int BWD_WORDS = GZ2_W + 16 * P16;      // 2160 words per wave
+static_assert(WAVES * BWD_WORDS >= WAVES * G_SLAB, "the gradient rows are combined in the staging LDS");
 
 DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -54,6 +56,7 @@ DEV int slot_word(int slot) {
     return SER_BASE0 + SER_STRIDE * type + 5 - tap;
 }
 DEV int swz(int s) { return 4 * ((s >> 1) & 3); }
+DEV int g_of_lane() { return (threadIdx.x & 63) >> 4; }
 
 struct Lane {
     int lane, j, g;
@@ -91,10 +94,11 @@ DEV void stage_series(float *ser, const float2 *__restrict__ iqrow, int64_t t0, 
 struct FwdWeights {
     float A1[2][8];   // W1 tile t, step s: lane (i, g) holds W1[16t + i][slot 4s + g]
     float A2[2][4];   // W2[i][16t + 4g + r]
-    float w3[2][4];   // W3[o][4g + r]
+    float A3[4];      // W3 with its two rows repeated at rows 4q, 4q+1 of a 16-row tile: every lane
+                      // group then finds z3_0, z3_1 in registers 0, 1 of the result (no cross-lane sum)
     f32x4 bias1[2];   // b1[16t + 4g + r]
     f32x4 bias2;      // b2[4g + r]
-    float b3[2];
+    f32x4 bias3;      // (b3_0, b3_1, 0, 0)
 };
 
 DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, int g) {
@@ -110,26 +114,38 @@ DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) w.A2[t][r] = wq[G_W2 + j * 32 + 16 * t + 4 * g + r];
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w.w3[o][r] = wq[G_W3 + o * 16 + 4 * g + r];
+    for (int r = 0; r < 4; ++r) w.A3[r] = (j & 3) < 2 ? wq[G_W3 + (j & 3) * 16 + 4 * g + r] : 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) w.bias1[t][r] = wq[G_B1 + 16 * t + 4 * g + r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) w.bias2[r] = wq[G_B2 + 4 * g + r];
-    w.b3[0] = wq[G_B3];
-    w.b3[1] = wq[G_B3 + 1];
+    w.bias3 = f32x4{wq[G_B3], wq[G_B3 + 1], 0.f, 0.f};
 }
 
 struct TileFwd {
-    f32x4 z1[2];   // pre-activations (sign gives the LeakyReLU mask)
+    f32x4 m1[2];   // LeakyReLU multipliers (1 or slope) of the pre-activations
     f32x4 h1[2];   // activations as fed to FC2 (quantised when QAT)
-    f32x4 z2;
+    f32x4 m2;
     f32x4 h2;
     float y[2];    // tanh output, identical in the four lanes of a sample
 };
+
+// tanh to fp32 rounding level: odd series below 0.1 (next term 62/2835 x^9 < 2e-11), above it
+// (1 - t) / (1 + t) with t = exp(-2|x|) (no cancellation left: 1 - t >= 0.18)
+DEV float tanh_f32(float x) {
+    const float ax = fabsf(x);
+    const float x2 = x * x;
+    const float small = x * __builtin_fmaf(x2, __builtin_fmaf(x2, __builtin_fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+    const float t = __builtin_amdgcn_exp2f(ax * -2.885390081777927f);   // exp(-2|x|)
+    const float big = copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), x);
+    return ax < 0.1f ? small : big;
+}
+
+DEV float swap16(float v) {   // value of lane ^ 16 (ds_swizzle bit mode: and 0x1f, or 0, xor 0x10)
+    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
+}
 
 // Forward of one 16-sample tile.  DEPTH limits how far it runs (1: through act1, 2: through act2,
 // >= 3: to the output).  boff[s] = byte offset of this lane's FC1 operand for step s in tile 0.
@@ -143,15 +159,18 @@ DEV void tile_forward(TileFwd &tf, const FwdWeights &w, const char *ser_bytes, c
         a0 = mfma4(w.A1[0][s], b, a0);
         a1 = mfma4(w.A1[1][s], b, a1);
     }
-    tf.z1[0] = a0;
-    tf.z1[1] = a1;
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int r = 0; r < 4; ++r) {
+        tf.m1[0][r] = a0[r] > 0.f ? 1.f : slope;
+        tf.m1[1][r] = a1[r] > 0.f ? 1.f : slope;
+    }
+    a0 *= tf.m1[0];
+    a1 *= tf.m1[1];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float h = lrelu(tf.z1[t][r], slope);
-            tf.h1[t][r] = (QAT && DEPTH >= 2) ? fq16(h, s1) : h;
-        }
+    for (int r = 0; r < 4; ++r) {
+        tf.h1[0][r] = (QAT && DEPTH >= 2) ? fq16(a0[r], s1) : a0[r];
+        tf.h1[1][r] = (QAT && DEPTH >= 2) ? fq16(a1[r], s1) : a1[r];
+    }
     if (DEPTH < 2) return;
     f32x4 c0 = w.bias2, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -159,22 +178,22 @@ DEV void tile_forward(TileFwd &tf, const FwdWeights &w, const char *ser_bytes, c
         c0 = mfma4(w.A2[0][r], tf.h1[0][r], c0);
         c1 = mfma4(w.A2[1][r], tf.h1[1][r], c1);
     }
-    tf.z2 = c0 + c1;
+    c0 += c1;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float h = lrelu(tf.z2[r], slope);
-        tf.h2[r] = (QAT && DEPTH >= 3) ? fq16(h, s2) : h;
-    }
+    for (int r = 0; r < 4; ++r) tf.m2[r] = c0[r] > 0.f ? 1.f : slope;
+    c0 *= tf.m2;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tf.h2[r] = (QAT && DEPTH >= 3) ? fq16(c0[r], s2) : c0[r];
     if (DEPTH < 3) return;
+    f32x4 z3 = w.bias3;
 #pragma unroll
-    for (int o = 0; o < 2; ++o) {
-        float p = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) p = __builtin_fmaf(w.w3[o][r], tf.h2[r], p);
-        p += __shfl_xor(p, 16);
-        p += __shfl_xor(p, 32);
-        tf.y[o] = tanhf(p + w.b3[o]);
-    }
+    for (int r = 0; r < 4; ++r) z3 = mfma4(w.A3[r], tf.h2[r], z3);
+    // each lane evaluates one tanh (output g & 1) and fetches the other from lane ^ 16
+    const bool odd = (g_of_lane() & 1) != 0;
+    const float mine = tanh_f32(odd ? z3[1] : z3[0]);
+    const float other = swap16(mine);
+    tf.y[0] = odd ? other : mine;
+    tf.y[1] = odd ? mine : other;
 }
 
 template <bool QAT, int DEPTH>
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_fwd_mfma(const float2 *__res
     __shared__ float lds[WAVES][SER_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     float *ser = lds[wave];
-    if (lane == 0) ser[ZERO_W] = 0.f;
+    ser[ZERO_W + lane] = 0.f;
     FwdWeights w;
     load_fwd_weights(w, wq, j, g);
     int boff[8];
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__res
     __shared__ __attribute__((aligned(16))) float lds[WAVES][BWD_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     float *ser = lds[wave];
-    if (lane == 0) ser[ZERO_W] = 0.f;
+    ser[ZERO_W + lane] = 0.f;
     FwdWeights w;
     load_fwd_weights(w, wq, j, g);
     float A2T[2][4];  // W2[4g + r][16t + i]
@@ -270,6 +289,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__res
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) A2T[t][r] = wq[G_W2 + (4 * g + r) * 32 + 16 * t + j];
+    const float A3T = g < 2 ? wq[G_W3 + g * 16 + j] : 0.f;   // W3^T as an A operand: k = output index = lane group
     int boff[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -320,41 +340,39 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__res
     for (int64_t chunk = (int64_t)blockIdx.x * WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * WAVES) {
         const int64_t row = chunk / cpr, t0 = (chunk - row * cpr) * CHUNK;
         stage_series<QAT>(ser, iq + row * S, t0, S, lane, s0);
+        // upstream gradient source for sample j of tile c: src[16 c]
+        const float2 *src = (MSE ? target : grad_out) + row * L + t0 + j;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (t0 + 16 * c >= L) break;
             TileFwd tf;
             tile_forward<QAT, 3>(tf, w, reinterpret_cast<const char *>(ser), boff, c, slope, s1, s2);
-            const int64_t t = t0 + 16 * c + j;
-            const bool valid = t < L;
+            const bool valid = (t0 + 16 * c + j) < L;
             float g0 = 0.f, g1 = 0.f;
             if (valid) {
+                const float2 v = src[16 * c];
                 if (MSE) {
                     float o0 = QAT ? fq16(tf.y[0], s3) : tf.y[0], o1 = QAT ? fq16(tf.y[1], s3) : tf.y[1];
-                    float2 tg = target[row * L + t];
-                    float d0 = o0 - tg.x, d1 = o1 - tg.y;
-                    if (g == 0) loss += d0 * d0 + d1 * d1;
+                    float d0 = o0 - v.x, d1 = o1 - v.y;
+                    loss += d0 * d0 + d1 * d1;          // counted in all four lanes of the sample
                     g0 = d0 * mse_scale;
                     g1 = d1 * mse_scale;
                 } else {
-                    float2 go = grad_out[row * L + t];
-                    g0 = go.x;
-                    g1 = go.y;
+                    g0 = v.x;
+                    g1 = v.y;
                 }
             }
             const float gz3_0 = g0 * (1.f - tf.y[0] * tf.y[0]), gz3_1 = g1 * (1.f - tf.y[1] * tf.y[1]);
-            if (g == 0) {
-                db3[0] += gz3_0;
-                db3[1] += gz3_1;
-            }
-            f32x4 gz2;
+            db3[0] += gz3_0;                            // identical in the four lane groups; group 0 is stored
+            db3[1] += gz3_1;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 dW3[0][r] = __builtin_fmaf(gz3_0, tf.h2[r], dW3[0][r]);
                 dW3[1][r] = __builtin_fmaf(gz3_1, tf.h2[r], dW3[1][r]);
-                float gh2 = __builtin_fmaf(gz3_1, w.w3[1][r], gz3_0 * w.w3[0][r]);
-                gz2[r] = gh2 * lrelu_mask(tf.z2[r], slope);
             }
+            // gh2^T = W3^T gz3^T: one MFMA with k = output index on the lane groups (groups 2, 3 multiply zeros)
+            f32x4 gz2 = mfma4(A3T, (g & 1) ? gz3_1 : gz3_0, f32x4{0.f, 0.f, 0.f, 0.f});
+            gz2 *= tf.m2;
             db2 += gz2;
             // gh1^T = W2^T gz2^T  (two row tiles of 16 h1-neurons)
             f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
@@ -363,12 +381,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__res
                 e0 = mfma4(A2T[0][r], gz2[r], e0);
                 e1 = mfma4(A2T[1][r], gz2[r], e1);
             }
-            f32x4 gz1[2];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                gz1[0][r] = e0[r] * lrelu_mask(tf.z1[0][r], slope);
-                gz1[1][r] = e1[r] * lrelu_mask(tf.z1[1][r], slope);
-            }
+            f32x4 gz1[2] = {e0 * tf.m1[0], e1 * tf.m1[1]};
             db1[0] += gz1[0];
             db1[1] += gz1[1];
             // lanes -> K axis: park [sample][neuron] tiles in LDS
@@ -400,8 +413,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__res
         }
     }
 
-    // ---- write this wave's partial gradient row
-    float *rowp = slab + ((int64_t)blockIdx.x * WAVES + wave) * G_SLAB;
+    // ---- partial gradient row of this wave -> LDS, the workgroup's four rows are summed, one row per
+    // workgroup goes to the slab (the staging regions are dead: every wave has left its loop)
+    __syncthreads();
+    float *comb = &lds[0][0];
+    float *rowp = comb + wave * G_SLAB;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -443,8 +459,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__res
             rowp[G_B3 + 1] = db3[1];
         }
     }
-    loss = wave_sum(loss);
+    loss = wave_sum(loss) * 0.25f;
     if (lane == 0) rowp[G_NP] = loss;
+    __syncthreads();
+    float *out_row = slab + (int64_t)blockIdx.x * G_SLAB;
+    for (int e = threadIdx.x; e <= G_NP; e += WAVES * 64)
+        out_row[e] = (comb[e] + comb[G_SLAB + e]) + (comb[2 * G_SLAB + e] + comb[3 * G_SLAB + e]);
 }
 
 }  // namespace
@@ -483,7 +503,7 @@ int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *t
     const float2 *iq = reinterpret_cast<const float2 *>(p.x);
     const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
     const int gridn = mfma_grid(n_chunks);
-    *n_partials = gridn * WAVES;
+    *n_partials = gridn;
     const dim3 grid(gridn), block(WAVES * 64);
     const bool mse = grad_out == nullptr;
     const float mse_scale = mse ? (float)(2.0 / (2.0 * (double)p.N)) : 0.f;

@@ -286,17 +286,30 @@ __global__ __launch_bounds__(BWD_TPB) void k_gen_bwd(const float *__restrict__ x
     if (tid == 0) row[G_NP] = loss;
 }
 
+// out[e] = sum over partial rows of slab[p][e] for e < n_out, and extra[0] = extra_scale * sum of column
+// n_out.  64 columns per workgroup; the four waves take every fourth row (coalesced 256-byte reads),
+// accumulate in double and are combined through LDS in a fixed order (bitwise reproducible).
 __global__ __launch_bounds__(256) void k_reduce_slab(const float *__restrict__ slab, int n_partials, int row_len,
                                                      int n_out, float *__restrict__ grads, float *__restrict__ loss,
                                                      float loss_scale) {
-    int e = blockIdx.x * 256 + threadIdx.x;
-    if (e > n_out) return;
+    __shared__ double part[4][64];
+    const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + c;
     double a = 0.0;
-    for (int p = 0; p < n_partials; ++p) a += (double)slab[(int64_t)p * row_len + e];
-    if (e < n_out)
-        grads[e] = (float)a;
-    else if (loss != nullptr)
-        loss[0] = (float)(a * (double)loss_scale);
+    if (e <= n_out) {
+        const float *p = slab + e;
+#pragma unroll 8
+        for (int r = s; r < n_partials; r += 4) a += (double)p[(int64_t)r * row_len];
+    }
+    part[s][c] = a;
+    __syncthreads();
+    if (s == 0 && e <= n_out) {
+        a = (part[0][c] + part[1][c]) + (part[2][c] + part[3][c]);
+        if (e < n_out)
+            grads[e] = (float)a;
+        else if (loss != nullptr)
+            loss[0] = (float)(a * (double)loss_scale);
+    }
 }
 
 // One wave: row r < 50 of the three weight matrices per lane.
@@ -394,7 +407,7 @@ int gen_valu_backward(const GenProblem &p, const float *grad_out, const float *t
 }
 
 int gen_reduce_slab(const float *slab, int n_partials, float *grads, float *loss, float loss_scale, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_slab, dim3((G_NP + 1 + 255) / 256), dim3(256), 0, st, slab, n_partials, G_SLAB, G_NP,
+    hipLaunchKernelGGL(k_reduce_slab, dim3((G_NP + 1 + 63) / 64), dim3(256), 0, st, slab, n_partials, G_SLAB, G_NP,
                        grads, loss, loss_scale);
     DPD_LAUNCH_CHECK();
     return DPD_OK;
@@ -402,7 +415,7 @@ int gen_reduce_slab(const float *slab, int n_partials, float *grads, float *loss
 
 int gen_reduce_slab_generic(const float *slab, int n_partials, int row_len, int n_out, float *grads, float *extra,
                             float extra_scale, hipStream_t st) {
-    hipLaunchKernelGGL(k_reduce_slab, dim3((n_out + 1 + 255) / 256), dim3(256), 0, st, slab, n_partials, row_len, n_out,
+    hipLaunchKernelGGL(k_reduce_slab, dim3((n_out + 1 + 63) / 64), dim3(256), 0, st, slab, n_partials, row_len, n_out,
                        grads, extra, extra_scale);
     DPD_LAUNCH_CHECK();
     return DPD_OK;

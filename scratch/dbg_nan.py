@@ -1,0 +1,26 @@
+import sys, torch
+sys.path.insert(0, '.')
+import dpd_amd
+from dpd_amd import _lib as L
+from dpd_amd.data import ofdm_rows
+from dpd_amd.models import TDNNGeneratorQAT
+dev = torch.device('cuda:0')
+torch.manual_seed(0)
+gen = TDNNGeneratorQAT().to(dev)
+B, S = int(sys.argv[1]) if len(sys.argv) > 1 else 16384, 1029
+iq = ofdm_rows(B, S, seed=1234, device=dev)
+tgt = iq[:, 5:, :].contiguous()
+params = [gen.fc1.weight, gen.fc1.bias, gen.fc2.weight, gen.fc2.bias, gen.fc3.weight, gen.fc3.bias]
+res = {}
+for impl in (2, 1, 2):
+    wq = torch.empty(1554, device=dev); absmax = torch.zeros(8, device=dev)
+    grads = torch.empty(1554, device=dev); loss = torch.zeros(1, device=dev)
+    st = L.stream()
+    L.call("dpd_gen_prepare_weights", *(L.fptr(p.detach()) for p in params), 0, L.fptr(wq), L.fptr(absmax), st)
+    _, wsp, wsn = L.workspace(dev)
+    L.call("dpd_gen_mse_step", L.fptr(iq), B, S, L.fptr(tgt), L.fptr(wq), 0.2, 0, L.fptr(absmax), L.fptr(grads), L.fptr(loss), wsp, wsn, impl, st)
+    torch.cuda.synchronize()
+    print(impl, 'loss', loss.item(), 'nan grads', torch.isnan(grads).sum().item(), 'absmax grad', grads.abs().max().item())
+    res.setdefault(impl, []).append(grads.clone())
+d = (res[2][0] - res[1][0]).abs().max().item()
+print('mfma vs valu max abs diff', d, 'rel', d / res[1][0].abs().max().item(), 'mfma repeat diff', (res[2][0]-res[2][1]).abs().max().item())
