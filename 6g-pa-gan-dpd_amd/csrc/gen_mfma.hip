@@ -25,6 +25,9 @@ namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int WAVES = 4;
+#ifndef BWD_WAVES_PER_SIMD
+#define BWD_WAVES_PER_SIMD 2        // measured: 2 resident waves per SIMD (<= 256 registers, no spills) beat 3 with spills
+#endif
 constexpr int CHUNK = 64;           // samples per wave iteration
 constexpr int SER_STRIDE = 71;      // words between series (71 = 7 mod 32: bank-disjoint operand reads)
 constexpr int SER_BASE0 = 5;
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(256) void k_iq_absmax(const float2 *__restrict__ iq
 
 // ------------------------------------------------------------------------------------ backward
 template <bool QAT, bool MSE>
-__global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
+__global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
                                                              int64_t cpr, int64_t n_chunks,
                                                              const float *__restrict__ wq, float slope,
                                                              const float *__restrict__ absmax,
@@ -469,9 +472,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_bwd_mfma(const float2 *__res
 
 }  // namespace
 
-static int mfma_grid(int64_t n_chunks) {
+static int mfma_grid(int64_t n_chunks, int per_cu = 2) {
     int64_t blocks = (n_chunks + WAVES - 1) / WAVES;
-    if (blocks > 512) blocks = 512;  // 2 workgroups per CU
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // resident workgroups per CU
     if (blocks < 1) blocks = 1;
     return (int)blocks;
 }
@@ -502,7 +505,7 @@ int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *t
                       hipStream_t st) {
     const float2 *iq = reinterpret_cast<const float2 *>(p.x);
     const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
-    const int gridn = mfma_grid(n_chunks);
+    const int gridn = mfma_grid(n_chunks, BWD_WAVES_PER_SIMD);
     *n_partials = gridn;
     const dim3 grid(gridn), block(WAVES * 64);
     const bool mse = grad_out == nullptr;

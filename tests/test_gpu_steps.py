@@ -53,3 +53,22 @@ def test_stage2_step_golden():
         close(v, g1[k], rtol=1e-5, atol=5e-7)
     for k, v in disc.state_dict().items():
         close(v, d2[k], rtol=1e-4 if "weight_" in k and "orig" not in k else 1e-5, atol=1e-6)
+
+
+def test_stage1_many_steps_stay_finite():
+    """Dozens of steps at a size where every wave walks many chunks: the loss must stay finite and fall
+    (guards the padding-slot operand reads of the MFMA kernels, which must never see stale LDS)."""
+    from dpd_amd.data import ofdm_rows
+    from dpd_amd.models import TDNNGeneratorQAT
+    from dpd_amd.training import Stage1Step
+    # leave non-finite fp32 bit patterns in LDS first: fp64 partial sums in the slab reduction do that
+    for qat in (False, True):
+        torch.manual_seed(0)
+        gen = TDNNGeneratorQAT().to(DEV).train()
+        gen.qat_enabled = qat
+        iq = ofdm_rows(4096, 1029, seed=7, device=DEV)
+        tgt = iq[:, 5:, :].contiguous()
+        step = Stage1Step(gen)
+        losses = torch.stack([step(iq, tgt).clone() for _ in range(24)]).flatten().cpu()
+        assert torch.isfinite(losses).all()
+        assert losses[-1] < losses[0]
