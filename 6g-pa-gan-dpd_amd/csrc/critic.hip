@@ -18,6 +18,28 @@
 int gen_reduce_slab_generic(const float *slab, int n_partials, int row_len, int n_out, float *grads, float *extra,
                             float extra_scale, hipStream_t st);
 
+int critic_mfma_forward(const float *x, const float *cond, int64_t N, const float *wb, float slope, float *score,
+                        float *score_sum, hipStream_t st);
+int critic_mfma_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope, const float *gscore,
+                         float gconst, float *grads, float *gx, float *ws, hipStream_t st);
+size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L);
+int critic_mfma_gp(const float *real, const float *fake, const float *cond, const float *alpha, int64_t B, int64_t L,
+                   const float *wb, float slope, float *gp, float *rownorm, float *grads, void *ws, hipStream_t st);
+
+// kernel family: 0 = by size (MFMA from 1024 samples), 1 = VALU, 2 = MFMA
+static int g_critic_impl = 0;
+static bool critic_use_mfma(int64_t N) { return g_critic_impl == 2 || (g_critic_impl == 0 && N >= 1024); }
+
+extern "C" int dpd_set_option(const char *name, int value) {
+    DPD_REQUIRE(name, DPD_ERR_INVALID_ARG, "set_option: null name");
+    if (__builtin_strcmp(name, "critic_impl") == 0 && value >= 0 && value <= 2) {
+        g_critic_impl = value;
+        return DPD_OK;
+    }
+    dpd_set_error("set_option: unknown option %s or bad value %d", name, value);
+    return DPD_ERR_INVALID_ARG;
+}
+
 namespace {
 
 constexpr int TPB = 64;               // one wave per block: the LDS panel is wave-private
@@ -397,6 +419,7 @@ extern "C" int dpd_critic_forward(const float *x, const float *cond, int64_t N, 
     hipStream_t st = as_stream(stream);
     if (score_sum) DPD_HIP(hipMemsetAsync(score_sum, 0, sizeof(float), st));
     if (N == 0) return DPD_OK;
+    if (critic_use_mfma(N)) return critic_mfma_forward(x, cond, N, wb, slope, score, score_sum, st);
     hipLaunchKernelGGL(k_critic_fwd, dim3(grid_for(N, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(x),
                        reinterpret_cast<const float2 *>(cond), N, wb, slope, score, score_sum);
     DPD_LAUNCH_CHECK();
@@ -413,6 +436,8 @@ extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N,
         if (grads) DPD_HIP(hipMemsetAsync(grads, 0, C_NP * sizeof(float), st));
         return DPD_OK;
     }
+    if (critic_use_mfma(N))
+        return critic_mfma_backward(x, cond, N, wb, slope, gscore, gconst, grads, gx, reinterpret_cast<float *>(ws), st);
     const int grid = grid_for(N, TPB, 1024);
     float *slab = reinterpret_cast<float *>(ws);
     constexpr size_t lds_bytes = (size_t)(C_NP + 3 + TPB * LP + TPB * RP) * sizeof(float);
@@ -453,6 +478,10 @@ extern "C" int dpd_critic_gp(const float *real, const float *fake, const float *
     if (N == 0) {
         DPD_HIP(hipMemsetAsync(grads, 0, C_NP * sizeof(float), st));
         return DPD_OK;
+    }
+    if (critic_use_mfma(N) && (L == 1 || (L & 15) == 0)) {
+        DPD_REQUIRE(ws_bytes >= critic_mfma_gp_ws_bytes(B, L), DPD_ERR_WORKSPACE, "critic_gp: workspace too small");
+        return critic_mfma_gp(real, fake, cond, alpha, B, L, wb, slope, gp, rownorm, grads, ws, st);
     }
     char *base = reinterpret_cast<char *>(ws);
     float *slab = reinterpret_cast<float *>(base);

@@ -1,0 +1,699 @@
+// Critic 4 -> 64 -> 32 -> 16 -> 1 on fp32 MFMA (v_mfma_f32_16x16x4_f32): forward, backward and the
+// gradient penalty with its double backward.  Semantics: reference models/discriminator.py:103-191
+// (see critic.hip for the formulas).
+//
+// Geometry as in the generator kernels: tiles of 16 samples, lane l = (g = l >> 4, j = l & 15),
+// every product computed transposed (D = W * X^T) so that a 16x16 result leaves lane (g, j) holding
+// neurons 4g..4g+3 of sample j, which is the B-operand layout of the next layer.  The A operands
+// (weights in MFMA lane order) do not fit registers next to the gradient accumulators, so the
+// workgroup keeps them in an LDS image, four k-steps per ds_read_b128.  The single-row products
+// (score, input gradient) use a replicated-row image so that the result lands in register 0 (0, 1)
+// of every lane group.  Weight gradients contract over samples: left and right factor tiles are
+// transposed through XOR-swizzled wave-private LDS tiles in three phases that share one buffer.
+#include "common.h"
+
+int gen_reduce_slab_generic(const float *slab, int n_partials, int row_len, int n_out, float *grads, float *extra,
+                            float extra_scale, hipStream_t st);
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+
+constexpr int WAVES = 4;
+// operand image: quads of four consecutive k-steps per lane
+constexpr int Q_A1 = 0;     // [t]            e = t : W1[16t + i][g]
+constexpr int Q_A2 = 1;     // [u][t]         e = r : W2[16u + i][16t + 4g + r]
+constexpr int Q_A3 = 9;     // [u]            e = r : W3[i][16u + 4g + r]
+constexpr int Q_A4 = 11;    //                e = r : (i & 3) == 0 ? W4[4g + r] : 0
+constexpr int Q_A3T = 12;   // [u]            e = r : W3[4g + r][16u + i]
+constexpr int Q_A2T = 14;   // [t][u]         e = r : W2[16u + 4g + r][16t + i]
+constexpr int Q_A1T = 22;   // [t]            e = r : (i & 3) < 2 ? W1[16t + 4g + r][i & 3] : 0
+constexpr int Q_B1 = 26;    // [t]            e = r : b1[16t + 4g + r]
+constexpr int Q_B2 = 30;    // [u]            e = r : b2[16u + 4g + r]
+constexpr int Q_B3 = 32;    //                e = r : b3[4g + r]
+constexpr int Q_B4 = 33;    //                e = 0 : b4, else 0
+constexpr int Q_W4 = 34;    //                e = r : W4[4g + r]
+constexpr int NQUAD = 35;
+constexpr int IMG_WORDS = NQUAD * 64 * 4;          // 8960
+// per-wave transposition buffer
+constexpr int P64 = 80, P32 = 48, P16 = 16;        // row pitches: 16 mod 32 -> rows s, s+1 hit different bank halves
+constexpr int LEFT_W = 0, RIGHT_W = 16 * P64, CONST_W = RIGHT_W + 16 * P32;
+constexpr int WAVE_WORDS = CONST_W + 16 * P16;     // 2304
+constexpr int LDS_WORDS = IMG_WORDS + WAVES * WAVE_WORDS;
+static_assert(LDS_WORDS >= WAVES * C_SLAB, "gradient rows are combined in the same LDS");
+
+DEV int swz(int s) { return 4 * ((s >> 1) & 3); }
+
+DEV void build_image(float *img, const float *__restrict__ wb) {
+    for (int idx = threadIdx.x; idx < NQUAD * 64; idx += WAVES * 64) {
+        const int q = idx >> 6, lane = idx & 63, i = lane & 15, g = lane >> 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float x = 0.f;
+            if (q == Q_A1) x = wb[C_W1 + (16 * e + i) * 4 + g];
+            else if (q < Q_A3) { int u = (q - Q_A2) >> 2, t = (q - Q_A2) & 3; x = wb[C_W2 + (16 * u + i) * 64 + 16 * t + 4 * g + e]; }
+            else if (q < Q_A4) { int u = q - Q_A3; x = wb[C_W3 + i * 32 + 16 * u + 4 * g + e]; }
+            else if (q == Q_A4) x = (i & 3) == 0 ? wb[C_W4 + 4 * g + e] : 0.f;
+            else if (q < Q_A2T) { int u = q - Q_A3T; x = wb[C_W3 + (4 * g + e) * 32 + 16 * u + i]; }
+            else if (q < Q_A1T) { int t = (q - Q_A2T) >> 1, u = (q - Q_A2T) & 1; x = wb[C_W2 + (16 * u + 4 * g + e) * 64 + 16 * t + i]; }
+            else if (q < Q_B1) { int t = q - Q_A1T; x = (i & 3) < 2 ? wb[C_W1 + (16 * t + 4 * g + e) * 4 + (i & 3)] : 0.f; }
+            else if (q < Q_B2) { int t = q - Q_B1; x = wb[C_B1 + 16 * t + 4 * g + e]; }
+            else if (q < Q_B3) { int u = q - Q_B2; x = wb[C_B2 + 16 * u + 4 * g + e]; }
+            else if (q == Q_B3) x = wb[C_B3 + 4 * g + e];
+            else if (q == Q_B4) x = e == 0 ? wb[C_B4] : 0.f;
+            else x = wb[C_W4 + 4 * g + e];
+            v[e] = x;
+        }
+        reinterpret_cast<f32x4 *>(img)[idx] = v;
+    }
+    __syncthreads();
+}
+
+DEV f32x4 quad(const float *img, int q, int lane) { return reinterpret_cast<const f32x4 *>(img)[q * 64 + lane]; }
+
+struct Acts {
+    f32x4 h1[4], h2[2], h3;   // post-activation; the LeakyReLU mask is read off the sign
+    float score;
+};
+
+DEV f32x4 lrelu4(f32x4 z, float slope) {
+    f32x4 h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) h[r] = z[r] > 0.f ? z[r] : z[r] * slope;
+    return h;
+}
+DEV f32x4 mask4(f32x4 h, float slope) {
+    f32x4 m;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) m[r] = h[r] > 0.f ? 1.f : slope;
+    return m;
+}
+
+// forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group)
+DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope) {
+    const f32x4 a1 = quad(img, Q_A1, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a.h1[t] = lrelu4(mfma4(a1[t], in, quad(img, Q_B1 + t, lane)), slope);
+    f32x4 z0 = quad(img, Q_B2, lane), z1 = quad(img, Q_B2 + 1, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const f32x4 w0 = quad(img, Q_A2 + t, lane), w1 = quad(img, Q_A2 + 4 + t, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            z0 = mfma4(w0[r], a.h1[t][r], z0);
+            z1 = mfma4(w1[r], a.h1[t][r], z1);
+        }
+    }
+    a.h2[0] = lrelu4(z0, slope);
+    a.h2[1] = lrelu4(z1, slope);
+    f32x4 y0 = quad(img, Q_B3, lane), y1 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 w30 = quad(img, Q_A3, lane), w31 = quad(img, Q_A3 + 1, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        y0 = mfma4(w30[r], a.h2[0][r], y0);
+        y1 = mfma4(w31[r], a.h2[1][r], y1);
+    }
+    a.h3 = lrelu4(y0 + y1, slope);
+    f32x4 s = quad(img, Q_B4, lane);
+    const f32x4 w4 = quad(img, Q_A4, lane);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s = mfma4(w4[r], a.h3[r], s);
+    a.score = s[0];
+}
+
+// back-propagation of an upstream vector through the three hidden layers:
+//   top[r] (16 values on neurons 4g + r of layer 3, already masked) -> d2[2] (layer 2, masked) -> d1[4] (layer 1, masked)
+DEV void chain_down(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2], const f32x4 (&m1)[4], f32x4 (&d2)[2],
+                    f32x4 (&d1)[4]) {
+    const f32x4 t0 = quad(img, Q_A3T, lane), t1 = quad(img, Q_A3T + 1, lane);
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        e0 = mfma4(t0[r], top[r], e0);
+        e1 = mfma4(t1[r], top[r], e1);
+    }
+    d2[0] = e0 * m2[0];
+    d2[1] = e1 * m2[1];
+    f32x4 f[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        f32x4 w[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) w[t] = quad(img, Q_A2T + 2 * t + u, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) f[t] = mfma4(w[t][r], d2[u][r], f[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) d1[t] = f[t] * m1[t];
+}
+
+// (W1[:, 0:2])^T d1 -> the two input-gradient components, in registers 0, 1 of every lane group
+DEV void to_input(const float *img, int lane, const f32x4 (&d1)[4], float &g0, float &g1) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; t += 2) {
+        const f32x4 w0 = quad(img, Q_A1T + t, lane), w1 = quad(img, Q_A1T + t + 1, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            a = mfma4(w0[r], d1[t][r], a);
+            b = mfma4(w1[r], d1[t + 1][r], b);
+        }
+    }
+    g0 = a[0] + b[0];
+    g1 = a[1] + b[1];
+}
+
+// ---- outer-product accumulation over the 16 samples of a tile --------------------------------------
+struct Accum {
+    f32x4 p1[4];       // [left64 tile t]            x right16
+    f32x4 p2[4][2];    // [left64 tile t][right32 u]
+    f32x4 p3[2];       // [left32 tile u]            x right16
+};
+
+struct Addr {
+    int wl64, wl32, wr32, wr16;     // byte offsets of this lane's float4 stores (row j, columns 4g..)
+    int rl64[4], rl32[4], rr32[4], rr16[4];   // byte offsets of operand reads for k-step q (row 4q + g, column j)
+};
+
+DEV void make_addr(Addr &ad, int j, int g) {
+    ad.wl64 = 4 * (LEFT_W + j * P64 + ((4 * g) ^ swz(j)));
+    ad.wl32 = 4 * (LEFT_W + j * P32 + ((4 * g) ^ swz(j)));
+    ad.wr32 = 4 * (RIGHT_W + j * P32 + ((4 * g) ^ swz(j)));
+    ad.wr16 = 4 * (RIGHT_W + j * P16 + ((4 * g) ^ swz(j)));
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int s = 4 * q + g, c = j ^ swz(s);
+        ad.rl64[q] = 4 * (LEFT_W + s * P64 + c);
+        ad.rl32[q] = 4 * (LEFT_W + s * P32 + c);
+        ad.rr32[q] = 4 * (RIGHT_W + s * P32 + c);
+        ad.rr16[q] = 4 * (RIGHT_W + s * P16 + c);
+    }
+}
+
+#define ST4(base, off, v) (*reinterpret_cast<f32x4 *>((base) + (off)) = (v))
+#define LD1(base, off) (*reinterpret_cast<const float *>((base) + (off)))
+
+// p1 += left64^T (x) cst16 where the 16-column right tile lives in the wave's constant region
+DEV void outer_p1(Accum &ac, char *wb, const Addr &ad, const f32x4 (&left)[4], const int (&rc)[4]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ST4(wb, ad.wl64 + 64 * t, left[t]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float r = LD1(wb, rc[q]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ac.p1[t] = mfma4(LD1(wb, ad.rl64[q] + 64 * t), r, ac.p1[t]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+DEV void outer_p2(Accum &ac, char *wb, const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) ST4(wb, ad.wl64 + 64 * t, left[t]);
+    ST4(wb, ad.wr32, right[0]);
+    ST4(wb, ad.wr32 + 64, right[1]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float r0 = LD1(wb, ad.rr32[q]), r1 = LD1(wb, ad.rr32[q] + 64);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const float l = LD1(wb, ad.rl64[q] + 64 * t);
+            ac.p2[t][0] = mfma4(l, r0, ac.p2[t][0]);
+            ac.p2[t][1] = mfma4(l, r1, ac.p2[t][1]);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+DEV void outer_p3(Accum &ac, char *wb, const Addr &ad, const f32x4 (&left)[2], f32x4 right) {
+    ST4(wb, ad.wl32, left[0]);
+    ST4(wb, ad.wl32 + 64, left[1]);
+    ST4(wb, ad.wr16, right);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float r = LD1(wb, ad.rr16[q]);
+        ac.p3[0] = mfma4(LD1(wb, ad.rl32[q]), r, ac.p3[0]);
+        ac.p3[1] = mfma4(LD1(wb, ad.rl32[q] + 64), r, ac.p3[1]);
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
+DEV void zero_accum(Accum &ac) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        ac.p1[t] = z;
+        ac.p2[t][0] = z;
+        ac.p2[t][1] = z;
+    }
+    ac.p3[0] = z;
+    ac.p3[1] = z;
+}
+
+// p1/p2/p3 and the per-lane vectors -> this wave's row of flat critic gradients (in LDS).
+// ncol1: columns of p1 that are W1 columns (4 for the backward, 2 for the penalty); bias1_col: column of p1
+// that holds the layer-1 bias gradient (-1: none).  v4/vb*: per-lane sums (already reduced over j).
+DEV void store_row(float *row, const Accum &ac, int j, int g, int ncol1, int bias1_col) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int n = 16 * t + 4 * g + r;
+            if (j < ncol1) row[C_W1 + n * 4 + j] = ac.p1[t][r];
+            if (j == bias1_col) row[C_B1 + n] = ac.p1[t][r];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) row[C_W2 + (16 * u + j) * 64 + n] = ac.p2[t][u][r];
+        }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row[C_W3 + j * 32 + 16 * u + 4 * g + r] = ac.p3[u][r];
+}
+
+DEV f32x4 sum_over_j(f32x4 v) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], off);
+    return v;
+}
+DEV float sum_over_j1(float v) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+DEV void combine_rows(float *lds, float *slab_row) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < C_NP; e += WAVES * 64)
+        slab_row[e] = (lds[e] + lds[C_SLAB + e]) + (lds[2 * C_SLAB + e] + lds[3 * C_SLAB + e]);
+}
+
+// ------------------------------------------------------------------------------------- kernels
+__global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__restrict__ x, const float *__restrict__ cond,
+                                                                int64_t N, const float *__restrict__ wb, float slope,
+                                                                float *__restrict__ score, float *__restrict__ part) {
+    __shared__ __attribute__((aligned(16))) float lds[IMG_WORDS];
+    build_image(lds, wb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int64_t ntiles = (N + 15) >> 4;
+    float acc = 0.f;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t n = tile * 16 + j;
+        const bool valid = n < N;
+        float in = 0.f;
+        if (valid) in = g < 2 ? x[2 * n + g] : cond[2 * n + g - 2];
+        Acts a;
+        tile_forward(a, lds, lane, in, slope);
+        if (valid && g == 0) {
+            if (score) score[n] = a.score;
+            acc += a.score;
+        }
+    }
+    if (part) {   // optional running sum: one atomic per wave (order-dependent in the last bits)
+        acc = wave_sum(acc);
+        if (lane == 0) atomicAdd(part, acc);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ part, int n, float *__restrict__ out,
+                                                      float scale) {
+    __shared__ double red[4];
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a += (double)part[i];
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (float)(((red[0] + red[1]) + (red[2] + red[3])) * (double)scale);
+}
+
+template <bool WGRAD, bool DX>
+__global__ __launch_bounds__(WAVES * 64) void k_critic_bwd_mfma(const float *__restrict__ x, const float *__restrict__ cond,
+                                                                int64_t N, const float *__restrict__ wb, float slope,
+                                                                const float *__restrict__ gscore, float gconst,
+                                                                float2 *__restrict__ gx, float *__restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // WGRAD: LDS_WORDS (> 64 KiB), else IMG_WORDS
+    build_image(lds, wb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + (WGRAD ? wave * WAVE_WORDS : 0));
+    Addr ad;
+    Accum ac;
+    int rc[4];          // constant-region reads: the input tile [sample][in0..3, 1, 0...]
+    f32x4 db2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, db3 = {0.f, 0.f, 0.f, 0.f}, dw4 = {0.f, 0.f, 0.f, 0.f};
+    float db4 = 0.f;
+    if (WGRAD) {
+        make_addr(ad, j, g);
+        zero_accum(ac);
+        float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
+        for (int k = lane; k < 256; k += 64) cst[k] = 0.f;
+        if (lane < 16) cst[lane * P16 + (4 ^ swz(lane))] = 1.f;          // column 4 = 1 -> layer-1 bias gradient
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rc[q] = 4 * (CONST_W + (4 * q + g) * P16 + (j ^ swz(4 * q + g)));
+    }
+    const f32x4 w4 = quad(lds, Q_W4, lane);
+    const int64_t ntiles = (N + 15) >> 4;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t n = tile * 16 + j;
+        const bool valid = n < N;
+        float in = 0.f, gs = 0.f;
+        if (valid) {
+            in = g < 2 ? x[2 * n + g] : cond[2 * n + g - 2];
+            gs = gscore ? gscore[n] : gconst;
+        }
+        Acts a;
+        tile_forward(a, lds, lane, in, slope);
+        f32x4 m1[4], m2[2];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) m1[t] = mask4(a.h1[t], slope);
+        m2[0] = mask4(a.h2[0], slope);
+        m2[1] = mask4(a.h2[1], slope);
+        const f32x4 gz3 = w4 * gs * mask4(a.h3, slope);
+        f32x4 gz2[2], gz1[4];
+        chain_down(lds, lane, gz3, m2, m1, gz2, gz1);
+        if (DX) {
+            float g0, g1;
+            to_input(lds, lane, gz1, g0, g1);
+            if (valid && g == 0) gx[n] = make_float2(g0, g1);
+        }
+        if (WGRAD) {
+            db2[0] += gz2[0];
+            db2[1] += gz2[1];
+            db3 += gz3;
+            dw4 += a.h3 * gs;
+            db4 += gs;
+            // the input tile: column g of row j
+            *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = in;
+            outer_p1(ac, wbuf, ad, gz1, rc);
+            outer_p2(ac, wbuf, ad, a.h1, gz2);
+            outer_p3(ac, wbuf, ad, a.h2, gz3);
+        }
+    }
+    if (!WGRAD) return;
+    __syncthreads();
+    float *row = lds + wave * C_SLAB;
+    store_row(row, ac, j, g, 4, 4);
+    db2[0] = sum_over_j(db2[0]);
+    db2[1] = sum_over_j(db2[1]);
+    db3 = sum_over_j(db3);
+    dw4 = sum_over_j(dw4);
+    db4 = sum_over_j1(db4);
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            row[C_B2 + 4 * g + r] = db2[0][r];
+            row[C_B2 + 16 + 4 * g + r] = db2[1][r];
+            row[C_B3 + 4 * g + r] = db3[r];
+            row[C_W4 + 4 * g + r] = dw4[r];
+        }
+        if (g == 0) row[C_B4] = db4;
+    }
+    combine_rows(lds, slab + (int64_t)blockIdx.x * C_SLAB);
+}
+
+// ---- gradient penalty, rows of L samples with L % 16 == 0 (or L == 1: every sample is its own row) -------
+// pass A: forward of x_hat, mask bits (one word per lane and tile), g per sample, sum |g|^2 per tile
+template <bool ROW1>
+__global__ __launch_bounds__(WAVES * 64) void k_gp_a_mfma(const float *__restrict__ real, const float *__restrict__ fake,
+                                                          const float *__restrict__ cond, const float *__restrict__ alpha,
+                                                          int64_t N, int64_t L, const float *__restrict__ wb, float slope,
+                                                          float2 *__restrict__ gout, unsigned *__restrict__ maskw,
+                                                          float *__restrict__ tile_sq) {
+    __shared__ __attribute__((aligned(16))) float lds[IMG_WORDS];
+    build_image(lds, wb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const f32x4 w4 = quad(lds, Q_W4, lane);
+    const int64_t ntiles = (N + 15) >> 4;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t n = tile * 16 + j;
+        const bool valid = n < N;
+        float in = 0.f;
+        if (valid) {
+            if (g < 2) {
+                const float al = alpha[ROW1 ? n : n / L];
+                in = al * real[2 * n + g] + (1.f - al) * fake[2 * n + g];
+            } else {
+                in = cond[2 * n + g - 2];
+            }
+        }
+        Acts a;
+        tile_forward(a, lds, lane, in, slope);
+        f32x4 m1[4], m2[2];
+        unsigned bits = 0u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            m1[t] = mask4(a.h1[t], slope);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bits |= (a.h1[t][r] > 0.f ? 1u : 0u) << (4 * t + r);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            m2[u] = mask4(a.h2[u], slope);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) bits |= (a.h2[u][r] > 0.f ? 1u : 0u) << (16 + 4 * u + r);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bits |= (a.h3[r] > 0.f ? 1u : 0u) << (24 + r);
+        const f32x4 v3 = w4 * mask4(a.h3, slope);
+        f32x4 v2[2], v1[4];
+        chain_down(lds, lane, v3, m2, m1, v2, v1);
+        float g0, g1;
+        to_input(lds, lane, v1, g0, g1);
+        if (!valid) { g0 = 0.f; g1 = 0.f; }
+        maskw[tile * 64 + lane] = bits;
+        if (valid && g == 0) gout[n] = make_float2(g0, g1);
+        if (!ROW1) {
+            float sq = sum_over_j1(g0 * g0 + g1 * g1);
+            if (lane == 0) tile_sq[tile] = sq;
+        }
+    }
+}
+
+// pass B (rows of L samples): per-row norm, coefficient and penalty term; one wave per row
+__global__ __launch_bounds__(64) void k_gp_rows_tiles(const float *__restrict__ tile_sq, int64_t B, int64_t tiles_per_row,
+                                                      float *__restrict__ rownorm, float *__restrict__ rowc,
+                                                      float *__restrict__ pen) {
+    for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+        float s = 0.f;
+        for (int64_t i = threadIdx.x; i < tiles_per_row; i += 64) s += tile_sq[b * tiles_per_row + i];
+        s = wave_sum(s);
+        if (threadIdx.x == 0) {
+            const float nrm = sqrtf(s);
+            rownorm[b] = nrm;
+            rowc[b] = nrm > 0.f ? 2.f * (nrm - 1.f) / (nrm * (float)B) : 0.f;
+            pen[b] = (nrm - 1.f) * (nrm - 1.f);
+        }
+    }
+}
+// pass B for rows of one sample
+__global__ __launch_bounds__(256) void k_gp_rows_single(const float2 *__restrict__ g, int64_t B, float *__restrict__ rownorm,
+                                                        float *__restrict__ rowc, float *__restrict__ pen) {
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+        const float2 v = g[b];
+        const float nrm = sqrtf(v.x * v.x + v.y * v.y);
+        rownorm[b] = nrm;
+        rowc[b] = nrm > 0.f ? 2.f * (nrm - 1.f) / (nrm * (float)B) : 0.f;
+        pen[b] = (nrm - 1.f) * (nrm - 1.f);
+    }
+}
+
+// pass C: reverse chain with gh = c_row * g and the weight gradient
+template <bool ROW1>
+__global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restrict__ gin, const unsigned *__restrict__ maskw,
+                                                          const float *__restrict__ rowc, int64_t N, int64_t L,
+                                                          const float *__restrict__ wb, float slope,
+                                                          float *__restrict__ slab) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // LDS_WORDS
+    build_image(lds, wb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + wave * WAVE_WORDS);
+    Addr ad;
+    Accum ac;
+    make_addr(ad, j, g);
+    zero_accum(ac);
+    int rc[4];
+    {
+        float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
+        for (int k = lane; k < 256; k += 64) cst[k] = 0.f;     // columns 2..15 of the gh tile stay 0
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rc[q] = 4 * (CONST_W + (4 * q + g) * P16 + (j ^ swz(4 * q + g)));
+    }
+    f32x4 dw4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 w4 = quad(lds, Q_W4, lane);
+    const f32x4 a1 = quad(lds, Q_A1, lane);
+    const int64_t ntiles = (N + 15) >> 4;
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+        const int64_t n = tile * 16 + j;
+        const bool valid = n < N;
+        const unsigned bits = maskw[tile * 64 + lane];
+        float gh0 = 0.f, gh1 = 0.f;
+        if (valid) {
+            const float2 gv = gin[n];
+            const float c = rowc[ROW1 ? n : n / L];
+            gh0 = c * gv.x;
+            gh1 = c * gv.y;
+        }
+        f32x4 m1[4], m2[2], m3;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m1[t][r] = ((bits >> (4 * t + r)) & 1u) ? 1.f : slope;
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) m2[u][r] = ((bits >> (16 + 4 * u + r)) & 1u) ? 1.f : slope;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) m3[r] = ((bits >> (24 + r)) & 1u) ? 1.f : slope;
+        const f32x4 v3 = w4 * m3;
+        f32x4 v2[2], v1[4];
+        chain_down(lds, lane, v3, m2, m1, v2, v1);
+        // du1 = (W1[:, 0:2] gh) * D1 : k = input column on the lane groups (groups 2, 3 carry zeros)
+        const float ghb = g == 0 ? gh0 : (g == 1 ? gh1 : 0.f);
+        f32x4 du1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) du1[t] = mfma4(a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f}) * m1[t];
+        // dv2 = W2 du1, du2 = dv2 * D2
+        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const f32x4 w0 = quad(lds, Q_A2 + t, lane), w1 = quad(lds, Q_A2 + 4 + t, lane);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                z0 = mfma4(w0[r], du1[t][r], z0);
+                z1 = mfma4(w1[r], du1[t][r], z1);
+            }
+        }
+        f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
+        // dv3 = W3 du2 ; dW4 += dv3 * D3
+        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 w30 = quad(lds, Q_A3, lane), w31 = quad(lds, Q_A3 + 1, lane);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            y0 = mfma4(w30[r], du2[0][r], y0);
+            y1 = mfma4(w31[r], du2[1][r], y1);
+        }
+        dw4 += (y0 + y1) * m3;
+        // gh tile: column g (< 2) of row j
+        if (g < 2) *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = ghb;
+        outer_p1(ac, wbuf, ad, v1, rc);
+        outer_p2(ac, wbuf, ad, du1, v2);
+        outer_p3(ac, wbuf, ad, du2, v3);
+    }
+    __syncthreads();
+    float *row = lds + wave * C_SLAB;
+    for (int e = lane; e < C_NP; e += 64) row[e] = 0.f;     // bias gradients and W1[:, 2:4] get no contribution
+    __builtin_amdgcn_wave_barrier();
+    store_row(row, ac, j, g, 2, -1);
+    dw4 = sum_over_j(dw4);
+    if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) row[C_W4 + 4 * g + r] = dw4[r];
+    }
+    combine_rows(lds, slab + (int64_t)blockIdx.x * C_SLAB);
+}
+
+int grid_tiles(int64_t N, int per_cu) {
+    int64_t blocks = (((N + 15) >> 4) + WAVES - 1) / WAVES;
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace
+
+// ---- launch interface used by critic.hip -------------------------------------------------------------
+template <typename K>
+static int allow_big_lds(K kernel, size_t bytes) {
+    DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return DPD_OK;
+}
+constexpr size_t BIG_LDS = (size_t)LDS_WORDS * sizeof(float), IMG_LDS = (size_t)IMG_WORDS * sizeof(float);
+
+static int init_attrs() {
+    static bool done = false;
+    if (done) return DPD_OK;
+    int rc = allow_big_lds(k_critic_bwd_mfma<true, true>, BIG_LDS);
+    rc = rc ? rc : allow_big_lds(k_critic_bwd_mfma<true, false>, BIG_LDS);
+    rc = rc ? rc : allow_big_lds(k_gp_c_mfma<true>, BIG_LDS);
+    rc = rc ? rc : allow_big_lds(k_gp_c_mfma<false>, BIG_LDS);
+    if (rc == DPD_OK) done = true;
+    return rc;
+}
+
+int critic_mfma_forward(const float *x, const float *cond, int64_t N, const float *wb, float slope, float *score,
+                        float *score_sum, hipStream_t st) {
+    const int grid = grid_tiles(N, 4);
+    hipLaunchKernelGGL(k_critic_fwd_mfma, dim3(grid), dim3(WAVES * 64), 0, st, x, cond, N, wb, slope, score, score_sum);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+int critic_mfma_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope, const float *gscore,
+                         float gconst, float *grads, float *gx, float *ws, hipStream_t st) {
+    float2 *gx2 = reinterpret_cast<float2 *>(gx);
+    int rc = init_attrs();
+    if (rc) return rc;
+    if (!grads) {
+        hipLaunchKernelGGL((k_critic_bwd_mfma<false, true>), dim3(grid_tiles(N, 4)), dim3(WAVES * 64), IMG_LDS, st, x, cond, N, wb,
+                           slope, gscore, gconst, gx2, nullptr);
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
+    const int grid = grid_tiles(N, 2);
+    if (gx)
+        hipLaunchKernelGGL((k_critic_bwd_mfma<true, true>), dim3(grid), dim3(WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
+                           gscore, gconst, gx2, ws);
+    else
+        hipLaunchKernelGGL((k_critic_bwd_mfma<true, false>), dim3(grid), dim3(WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
+                           gscore, gconst, gx2, ws);
+    DPD_LAUNCH_CHECK();
+    return gen_reduce_slab_generic(ws, grid, C_SLAB, C_NP, grads, nullptr, 1.f, st);
+}
+
+// ws layout: slab (512 rows) | mask words [ntiles * 64] | g [N] float2 | tile_sq [ntiles] | rowc [B] | pen [B]
+size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L) {
+    const int64_t N = B * L, nt = (N + 15) >> 4;
+    return (size_t)512 * C_SLAB * 4 + (size_t)nt * 64 * 4 + (size_t)N * 8 + (size_t)nt * 4 + (size_t)B * 8 + 1024;
+}
+
+int critic_mfma_gp(const float *real, const float *fake, const float *cond, const float *alpha, int64_t B, int64_t L,
+                   const float *wb, float slope, float *gp, float *rownorm, float *grads, void *ws, hipStream_t st) {
+    const int64_t N = B * L, nt = (N + 15) >> 4;
+    char *base = reinterpret_cast<char *>(ws);
+    float *slab = reinterpret_cast<float *>(base);
+    size_t off = (size_t)512 * C_SLAB * 4;
+    unsigned *maskw = reinterpret_cast<unsigned *>(base + off); off += (size_t)nt * 64 * 4;
+    float2 *g = reinterpret_cast<float2 *>(base + off); off += (size_t)N * 8;
+    float *tile_sq = reinterpret_cast<float *>(base + off); off += (size_t)nt * 4;
+    float *rowc = reinterpret_cast<float *>(base + off); off += (size_t)B * 4;
+    float *pen = reinterpret_cast<float *>(base + off);
+    const bool row1 = (L == 1);
+    int rc = init_attrs();
+    if (rc) return rc;
+    const int ga = grid_tiles(N, 4);
+    if (row1)
+        hipLaunchKernelGGL((k_gp_a_mfma<true>), dim3(ga), dim3(WAVES * 64), 0, st, real, fake, cond, alpha, N, L, wb, slope,
+                           g, maskw, tile_sq);
+    else
+        hipLaunchKernelGGL((k_gp_a_mfma<false>), dim3(ga), dim3(WAVES * 64), 0, st, real, fake, cond, alpha, N, L, wb, slope,
+                           g, maskw, tile_sq);
+    DPD_LAUNCH_CHECK();
+    if (row1)
+        hipLaunchKernelGGL(k_gp_rows_single, dim3(grid_for(B, 256, 1024)), dim3(256), 0, st, g, B, rownorm, rowc, pen);
+    else
+        hipLaunchKernelGGL(k_gp_rows_tiles, dim3(grid_for(B, 1, 4096)), dim3(64), 0, st, tile_sq, B, L / 16, rownorm, rowc, pen);
+    DPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, pen, (int)B, gp, 1.0f / (float)B);
+    DPD_LAUNCH_CHECK();
+    const int gc = grid_tiles(N, 2);
+    if (row1)
+        hipLaunchKernelGGL((k_gp_c_mfma<true>), dim3(gc), dim3(WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab);
+    else
+        hipLaunchKernelGGL((k_gp_c_mfma<false>), dim3(gc), dim3(WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab);
+    DPD_LAUNCH_CHECK();
+    return gen_reduce_slab_generic(slab, gc, C_SLAB, C_NP, grads, nullptr, 1.f, st);
+}

@@ -47,6 +47,9 @@ extern "C" {
 const char *dpd_last_error(void);
 int dpd_version(void);
 
+/* Test / tuning knob, process-wide.  "critic_impl": 0 = choose by size, 1 = VALU kernels, 2 = MFMA kernels. */
+int dpd_set_option(const char *name, int value);
+
 /* Scratch size in bytes for the ws-taking entry points: dpd_workspace_bytes(0) suffices for every
  * call except dpd_critic_gp, which needs dpd_workspace_bytes(B * L). */
 size_t dpd_workspace_bytes(int64_t n_samples);

@@ -10,6 +10,15 @@ from gpu_util import DEV, T, close, load_golden, sd
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[1, 2], ids=["valu", "mfma"])
+def critic_impl(request):
+    """Run the test once per critic kernel family (sizes here are below the automatic MFMA threshold)."""
+    from dpd_amd import _lib as L
+    L.call("dpd_set_option", b"critic_impl", request.param)
+    yield request.param
+    L.call("dpd_set_option", b"critic_impl", 0)
+
+
 def test_pa_twin_golden():
     from dpd_amd.models import PADigitalTwin
     g = load_golden("g5_pa")
@@ -69,7 +78,7 @@ def test_critic_init_matches_reference_rng():
         assert torch.equal(v, sd(g, "nosn__")[k]), k
 
 
-def test_critic_forward_backward_golden():
+def test_critic_forward_backward_golden(critic_impl):
     g = load_golden("g6_critic")
     d = _load_critic(g, "sd0__")
     x2, c2, x3, c3 = (T(g[k]) for k in ("x2", "c2", "x3", "c3"))
@@ -96,7 +105,7 @@ def test_critic_forward_backward_golden():
     close(dn.to(DEV)(x3, c3), g["nosn_out3"], rtol=1e-5, atol=1e-5 * np.abs(g["nosn_out3"]).max())
 
 
-def test_gradient_penalty_and_losses_golden():
+def test_gradient_penalty_and_losses_golden(critic_impl):
     from dpd_amd.models import WassersteinLoss, compute_gradient_penalty
     g = load_golden("g7_wgan_gp")
     d = _load_critic(g, "sd0__")
@@ -135,8 +144,8 @@ def test_gradient_penalty_and_losses_golden():
     assert torch.isfinite(compute_gradient_penalty(d, real, fake, cond, dev))
 
 
-@pytest.mark.parametrize("shape", [(3, 1), (5, 77), (2, 1024)])
-def test_gradient_penalty_vs_oracle_ragged(shape):
+@pytest.mark.parametrize("shape", [(3, 1), (37, 1), (5, 77), (2, 1024), (3, 48)])
+def test_gradient_penalty_vs_oracle_ragged(shape, critic_impl):
     """Row lengths that are not multiples of the 64-sample tile; [B, 2] inputs are rows of one sample."""
     from oracle import critic as oc
     from dpd_amd.models import Discriminator, compute_gradient_penalty
@@ -166,3 +175,36 @@ def test_gradient_penalty_vs_oracle_ragged(shape):
     gp.backward()
     for lin, rg in zip(d._layers(), ref_g):
         close(lin.weight_orig.grad, rg, rtol=3e-4, atol=3e-6)
+
+
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099])
+def test_critic_ragged_sizes_vs_oracle(n, critic_impl):
+    """Sample counts around the 16-sample tile: forward, input gradient and weight gradient."""
+    from oracle import critic as oc
+    from dpd_amd.models import Discriminator
+    torch.manual_seed(n)
+    d = Discriminator()
+    with torch.no_grad():
+        for nm, p in d.named_parameters():
+            if nm.endswith("bias"):
+                p.uniform_(-0.2, 0.2)
+    layers = oc.layers_from_state_dict(d.state_dict())
+    for l in layers:
+        l["weight_orig"].requires_grad_(True); l["bias"].requires_grad_(True)
+    gen = torch.Generator().manual_seed(n + 1)
+    x, c, gs = torch.randn(n, 2, generator=gen), torch.randn(n, 2, generator=gen), torch.randn(n, 1, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    ref = oc.critic_forward(layers, xr, c, training=False)
+    ins = [xr] + [t for l in layers for t in (l["bias"], l["weight_orig"])]
+    rg = torch.autograd.grad(ref, ins, gs)
+    d = d.to(DEV).eval()
+    xg = x.to(DEV).requires_grad_(True)
+    out = d(xg, c.to(DEV))
+    scale = float(ref.abs().max())
+    close(out, ref.detach(), rtol=1e-5, atol=1e-5 * scale)
+    out.backward(gs.to(DEV))
+    close(xg.grad, rg[0], rtol=1e-4, atol=1e-5 * float(rg[0].abs().max()))
+    i = 1
+    for lin in d._layers():
+        close(lin.bias.grad, rg[i], rtol=3e-4, atol=1e-5 * float(rg[i].abs().max())); i += 1
+        close(lin.weight_orig.grad, rg[i], rtol=3e-4, atol=1e-5 * float(rg[i].abs().max())); i += 1

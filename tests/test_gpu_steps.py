@@ -31,7 +31,17 @@ def test_stage1_step_golden(tag, qat, impl):
         close(v, ref[k], rtol=1e-5, atol=3e-7)
 
 
-def test_stage2_step_golden():
+@pytest.mark.parametrize("critic_impl", [1, 2], ids=["valu", "mfma"])
+def test_stage2_step_golden(critic_impl):
+    from dpd_amd import _lib as L
+    L.call("dpd_set_option", b"critic_impl", critic_impl)
+    try:
+        _stage2_step_golden()
+    finally:
+        L.call("dpd_set_option", b"critic_impl", 0)
+
+
+def _stage2_step_golden():
     from dpd_amd.models import Discriminator
     from dpd_amd.training import Stage2Step
     g = load_golden("g10_steps")
