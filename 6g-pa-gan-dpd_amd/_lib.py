@@ -32,7 +32,7 @@ PROTOTYPES = {
     "dpd_pa_backward": [c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "dpd_gen_pa_forward": [c_p, c_l, c_l, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "dpd_critic_forward": [c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p],
-    "dpd_critic_backward": [c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_sz, c_p],
+    "dpd_critic_backward": [c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p],
     "dpd_critic_gp": [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p],
     "dpd_spectral_stats": [c_p, c_p, c_l, c_l, c_p, c_p, c_p],
     "dpd_spectral_backward": [c_p, c_p, c_l, c_l, c_p, c_p, c_p, c_p],

@@ -21,7 +21,7 @@ int gen_reduce_slab_generic(const float *slab, int n_partials, int row_len, int 
 int critic_mfma_forward(const float *x, const float *cond, int64_t N, const float *wb, float slope, float *score,
                         float *score_sum, hipStream_t st);
 int critic_mfma_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope, const float *gscore,
-                         float gconst, float *grads, float *gx, float *ws, hipStream_t st);
+                         float gconst, float *grads, float *gx, float *score_sum, float *ws, hipStream_t st);
 size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L);
 int critic_mfma_gp(const float *real, const float *fake, const float *cond, const float *alpha, int64_t B, int64_t L,
                    const float *wb, float slope, float *gp, float *rownorm, float *grads, void *ws, hipStream_t st);
@@ -148,7 +148,8 @@ template <bool WGRAD>
 __global__ __launch_bounds__(TPB) void k_critic_bwd(const float2 *__restrict__ x, const float2 *__restrict__ cond,
                                                     int64_t N, const float *__restrict__ wb, float slope,
                                                     const float *__restrict__ gscore, float gconst,
-                                                    float2 *__restrict__ gx, float *__restrict__ slab) {
+                                                    float2 *__restrict__ gx, float *__restrict__ slab,
+                                                    float *__restrict__ score_sum) {
     extern __shared__ float dyn_lds[];   // > 64 KiB in total: launched with an explicit dynamic size
     float *sw = dyn_lds, *lp = sw + (C_NP + 3), *rp = lp + TPB * LP;
     load_wb(sw, wb);
@@ -156,6 +157,7 @@ __global__ __launch_bounds__(TPB) void k_critic_bwd(const float2 *__restrict__ x
     float acc[EPT];
 #pragma unroll
     for (int i = 0; i < EPT; ++i) acc[i] = 0.f;
+    float ssum = 0.f;
     const int64_t ntiles = (N + TPB - 1) / TPB;
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t n = tile * TPB + tid;
@@ -165,6 +167,7 @@ __global__ __launch_bounds__(TPB) void k_critic_bwd(const float2 *__restrict__ x
             float2 a = x[n], c = cond[n];
             f.in[0] = a.x; f.in[1] = a.y; f.in[2] = c.x; f.in[3] = c.y;
             critic_fwd(f, sw, slope);
+            ssum += f.score;
             const float gs = gscore ? gscore[n] : gconst;
 #pragma unroll
             for (int k = 0; k < 4; ++k) r[k] = f.in[k];
@@ -219,6 +222,10 @@ __global__ __launch_bounds__(TPB) void k_critic_bwd(const float2 *__restrict__ x
             panel_accumulate<LP, RP>(lp, rp, tid, acc, [](int e, int &lc, int &rc) { entry_cols_bwd(e, lc, rc); });
             __syncthreads();
         }
+    }
+    if (score_sum) {   // optional sum of scores: one atomic per wave (order-dependent in the last bits)
+        ssum = wave_sum(ssum);
+        if (tid == 0) atomicAdd(score_sum, ssum);
     }
     if (!WGRAD) return;
     float *row = slab + (int64_t)blockIdx.x * C_SLAB;
@@ -427,17 +434,19 @@ extern "C" int dpd_critic_forward(const float *x, const float *cond, int64_t N, 
 }
 
 extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope,
-                                   const float *gscore, float gconst, float *grads, float *gx, void *ws,
-                                   size_t ws_bytes, void *stream) {
+                                   const float *gscore, float gconst, float *grads, float *gx, float *score_sum,
+                                   void *ws, size_t ws_bytes, void *stream) {
     DPD_REQUIRE(x && cond && wb && (grads || gx), DPD_ERR_INVALID_ARG, "critic_backward: null pointer");
     DPD_REQUIRE(!grads || (ws && ws_bytes >= dpd_workspace_bytes(0)), DPD_ERR_WORKSPACE, "critic_backward: workspace too small");
     hipStream_t st = as_stream(stream);
+    if (score_sum) DPD_HIP(hipMemsetAsync(score_sum, 0, sizeof(float), st));
     if (N <= 0) {
         if (grads) DPD_HIP(hipMemsetAsync(grads, 0, C_NP * sizeof(float), st));
         return DPD_OK;
     }
     if (critic_use_mfma(N))
-        return critic_mfma_backward(x, cond, N, wb, slope, gscore, gconst, grads, gx, reinterpret_cast<float *>(ws), st);
+        return critic_mfma_backward(x, cond, N, wb, slope, gscore, gconst, grads, gx, score_sum,
+                                    reinterpret_cast<float *>(ws), st);
     const int grid = grid_for(N, TPB, 1024);
     float *slab = reinterpret_cast<float *>(ws);
     constexpr size_t lds_bytes = (size_t)(C_NP + 3 + TPB * LP + TPB * RP) * sizeof(float);
@@ -452,13 +461,13 @@ extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N,
     if (!grads) {   // input gradient only (generator update): no panel reduction, no slab
         hipLaunchKernelGGL(k_critic_bwd<false>, dim3(grid_for(N, TPB, 4096)), dim3(TPB), lds_bytes, st,
                            reinterpret_cast<const float2 *>(x), reinterpret_cast<const float2 *>(cond), N, wb, slope,
-                           gscore, gconst, reinterpret_cast<float2 *>(gx), slab);
+                           gscore, gconst, reinterpret_cast<float2 *>(gx), slab, score_sum);
         DPD_LAUNCH_CHECK();
         return DPD_OK;
     }
     hipLaunchKernelGGL(k_critic_bwd<true>, dim3(grid), dim3(TPB), lds_bytes, st, reinterpret_cast<const float2 *>(x),
                        reinterpret_cast<const float2 *>(cond), N, wb, slope, gscore, gconst,
-                       reinterpret_cast<float2 *>(gx), slab);
+                       reinterpret_cast<float2 *>(gx), slab, score_sum);
     DPD_LAUNCH_CHECK();
     return gen_reduce_slab_generic(slab, grid, C_SLAB, C_NP, grads, nullptr, 1.f, st);
 }

@@ -291,7 +291,7 @@ DEV float sum_over_j1(float v) {
 
 DEV void combine_rows(float *lds, float *slab_row) {
     __syncthreads();
-    for (int e = threadIdx.x; e < C_NP; e += WAVES * 64)
+    for (int e = threadIdx.x; e <= C_NP; e += WAVES * 64)
         slab_row[e] = (lds[e] + lds[C_SLAB + e]) + (lds[2 * C_SLAB + e] + lds[3 * C_SLAB + e]);
 }
 
@@ -337,7 +337,8 @@ template <bool WGRAD, bool DX>
 __global__ __launch_bounds__(WAVES * 64) void k_critic_bwd_mfma(const float *__restrict__ x, const float *__restrict__ cond,
                                                                 int64_t N, const float *__restrict__ wb, float slope,
                                                                 const float *__restrict__ gscore, float gconst,
-                                                                float2 *__restrict__ gx, float *__restrict__ slab) {
+                                                                float2 *__restrict__ gx, float *__restrict__ slab,
+                                                                float *__restrict__ score_sum) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // WGRAD: LDS_WORDS (> 64 KiB), else IMG_WORDS
     build_image(lds, wb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
@@ -357,6 +358,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_bwd_mfma(const float *__r
         for (int q = 0; q < 4; ++q) rc[q] = 4 * (CONST_W + (4 * q + g) * P16 + (j ^ swz(4 * q + g)));
     }
     const f32x4 w4 = quad(lds, Q_W4, lane);
+    float ssum = 0.f;
     const int64_t ntiles = (N + 15) >> 4;
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
         const int64_t n = tile * 16 + j;
@@ -368,6 +370,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_bwd_mfma(const float *__r
         }
         Acts a;
         tile_forward(a, lds, lane, in, slope);
+        ssum += (valid && g == 0) ? a.score : 0.f;
         f32x4 m1[4], m2[2];
 #pragma unroll
         for (int t = 0; t < 4; ++t) m1[t] = mask4(a.h1[t], slope);
@@ -394,10 +397,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_bwd_mfma(const float *__r
             outer_p3(ac, wbuf, ad, a.h2, gz3);
         }
     }
-    if (!WGRAD) return;
+    if (!WGRAD) {
+        if (score_sum) {   // no slab in this variant: one atomic per wave (order-dependent in the last bits)
+            ssum = wave_sum(ssum);
+            if (lane == 0) atomicAdd(score_sum, ssum);
+        }
+        return;
+    }
     __syncthreads();
     float *row = lds + wave * C_SLAB;
     store_row(row, ac, j, g, 4, 4);
+    ssum = wave_sum(ssum);
+    if (lane == 0) row[C_NP] = ssum;            // extra slab column: sum of scores, reduced in a fixed order
     db2[0] = sum_over_j(db2[0]);
     db2[1] = sum_over_j(db2[1]);
     db3 = sum_over_j(db3);
@@ -586,7 +597,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
     }
     __syncthreads();
     float *row = lds + wave * C_SLAB;
-    for (int e = lane; e < C_NP; e += 64) row[e] = 0.f;     // bias gradients and W1[:, 2:4] get no contribution
+    for (int e = lane; e <= C_NP; e += 64) row[e] = 0.f;    // bias gradients and W1[:, 2:4] get no contribution
     __builtin_amdgcn_wave_barrier();
     store_row(row, ac, j, g, 2, -1);
     dw4 = sum_over_j(dw4);
@@ -633,25 +644,25 @@ int critic_mfma_forward(const float *x, const float *cond, int64_t N, const floa
 }
 
 int critic_mfma_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope, const float *gscore,
-                         float gconst, float *grads, float *gx, float *ws, hipStream_t st) {
+                         float gconst, float *grads, float *gx, float *score_sum, float *ws, hipStream_t st) {
     float2 *gx2 = reinterpret_cast<float2 *>(gx);
     int rc = init_attrs();
     if (rc) return rc;
     if (!grads) {
         hipLaunchKernelGGL((k_critic_bwd_mfma<false, true>), dim3(grid_tiles(N, 4)), dim3(WAVES * 64), IMG_LDS, st, x, cond, N, wb,
-                           slope, gscore, gconst, gx2, nullptr);
+                           slope, gscore, gconst, gx2, nullptr, score_sum);
         DPD_LAUNCH_CHECK();
         return DPD_OK;
     }
     const int grid = grid_tiles(N, 2);
     if (gx)
         hipLaunchKernelGGL((k_critic_bwd_mfma<true, true>), dim3(grid), dim3(WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
-                           gscore, gconst, gx2, ws);
+                           gscore, gconst, gx2, ws, score_sum);
     else
         hipLaunchKernelGGL((k_critic_bwd_mfma<true, false>), dim3(grid), dim3(WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
-                           gscore, gconst, gx2, ws);
+                           gscore, gconst, gx2, ws, score_sum);
     DPD_LAUNCH_CHECK();
-    return gen_reduce_slab_generic(ws, grid, C_SLAB, C_NP, grads, nullptr, 1.f, st);
+    return gen_reduce_slab_generic(ws, grid, C_SLAB, C_NP, grads, score_sum, 1.f, st);
 }
 
 // ws layout: slab (512 rows) | mask words [ntiles * 64] | g [N] float2 | tile_sq [ntiles] | rowc [B] | pen [B]

@@ -86,8 +86,42 @@ class _CriticFn(torch.autograd.Function):
         gx = torch.empty_like(xc) if ctx.need_x else None
         _, wsp, wsn = L.workspace(xc.device)
         L.call("dpd_critic_backward", L.fptr(xc), L.fptr(cc), N, L.fptr(wbc), ctx.slope, L.fptr(L.as_f32(gscore)), 0.0,
-               L.fptr(grads), L.fptr(gx), wsp, wsn, L.stream())
+               L.fptr(grads), L.fptr(gx), L.c_p(0), wsp, wsn, L.stream())
         return gx, None, grads, None
+
+
+class _CriticMeanFn(torch.autograd.Function):
+    """mean_n critic(x, cond; wb) with its gradients formed in the same kernel pass: the mean is linear in
+    the scores, so the upstream gradient of every score is the constant 1/N and the backward of this
+    function only scales the saved gradients."""
+
+    @staticmethod
+    def forward(ctx, x, cond, wb, slope):
+        L.need_gpu(x, cond, wb)
+        xc, cc, wbc = L.as_f32(x), L.as_f32(cond), L.as_f32(wb)
+        N = xc.shape[0]
+        need_w, need_x = wb.requires_grad, x.requires_grad
+        ssum = torch.zeros(1, dtype=torch.float32, device=xc.device)
+        if not (need_w or need_x):
+            L.call("dpd_critic_forward", L.fptr(xc), L.fptr(cc), N, L.fptr(wbc), float(slope), L.c_p(0), L.fptr(ssum),
+                   L.stream())
+            return ssum[0] / N
+        grads = torch.empty(L.CRITIC_NPARAM, dtype=torch.float32, device=xc.device) if need_w else None
+        gx = torch.empty_like(xc) if need_x else None
+        _, wsp, wsn = L.workspace(xc.device)
+        L.call("dpd_critic_backward", L.fptr(xc), L.fptr(cc), N, L.fptr(wbc), float(slope), L.c_p(0), 1.0 / N,
+               L.fptr(grads), L.fptr(gx), L.fptr(ssum), wsp, wsn, L.stream())
+        ctx.save_for_backward(*(t for t in (grads, gx) if t is not None))
+        ctx.flags = (need_w, need_x)
+        return ssum[0] / N
+
+    @staticmethod
+    def backward(ctx, g):
+        need_w, need_x = ctx.flags
+        saved = list(ctx.saved_tensors)
+        grads = saved.pop(0) if need_w else None
+        gx = saved.pop(0) if need_x else None
+        return (gx * g if need_x else None), None, (grads * g if need_w else None), None
 
 
 class _GradPenaltyFn(torch.autograd.Function):
@@ -151,6 +185,13 @@ class Discriminator(nn.Module):
             parts += [w.reshape(-1), lin.bias]
         return torch.cat(parts)
 
+    def mean_score(self, x: torch.Tensor, condition: torch.Tensor) -> torch.Tensor:
+        """mean over all samples of forward(x, condition), fused with its backward (one kernel pass).
+        Counts as one forward for the spectral-norm power iteration."""
+        if x.dim() == 3:
+            x, condition = x.reshape(-1, 2), condition.reshape(-1, 2)
+        return _CriticMeanFn.apply(x, condition, self.flat_weights(), self.leaky_slope)
+
     def forward(self, x: torch.Tensor, condition: torch.Tensor) -> torch.Tensor:
         shape = None
         if x.dim() == 3:
@@ -182,21 +223,21 @@ class WassersteinLoss:
 
     def discriminator_loss(self, discriminator, real_samples, fake_samples, condition, device,
                            alpha: Optional[torch.Tensor] = None, sync_info: bool = True) -> Tuple[torch.Tensor, dict]:
-        real_score = discriminator(real_samples, condition)
-        fake_score = discriminator(fake_samples.detach(), condition)
-        w_distance = real_score.mean() - fake_score.mean()
+        real_mean = discriminator.mean_score(real_samples, condition)
+        fake_mean = discriminator.mean_score(fake_samples.detach(), condition)
+        w_distance = real_mean - fake_mean
         d_loss = -w_distance
         gp = compute_gradient_penalty(discriminator, real_samples, fake_samples, condition, device, alpha=alpha)
         total = d_loss + self.gp_weight * gp
-        vals = dict(d_loss=d_loss, gp=gp, w_distance=w_distance, real_score=real_score.mean(), fake_score=fake_score.mean())
+        vals = dict(d_loss=d_loss, gp=gp, w_distance=w_distance, real_score=real_mean, fake_score=fake_mean)
         # the reference returns python floats (one host sync each); sync_info=False keeps device scalars
         info = {k: (v.item() if sync_info else v.detach()) for k, v in vals.items()}
         return total, info
 
     def generator_loss(self, discriminator, fake_samples, condition, sync_info: bool = True) -> Tuple[torch.Tensor, dict]:
-        fake_score = discriminator(fake_samples, condition)
-        g_loss = -fake_score.mean()
-        vals = dict(g_loss=g_loss, fake_score=fake_score.mean())
+        fake_mean = discriminator.mean_score(fake_samples, condition)
+        g_loss = -fake_mean
+        vals = dict(g_loss=g_loss, fake_score=fake_mean)
         return g_loss, {k: (v.item() if sync_info else v.detach()) for k, v in vals.items()}
 
 

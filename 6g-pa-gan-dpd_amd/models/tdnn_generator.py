@@ -262,11 +262,18 @@ class TDNNGeneratorQAT(_GeneratorBase):
         if self.qat_enabled and (self.weight_bits != 16 or self.activation_bits != 16):
             raise NotImplementedError("the HIP kernels quantise to 16 bits (the reference default)")
         out, absmax = self._run(x, self.qat_enabled, pre_assembled)
-        if self.qat_enabled and self.training:
+        self._last_absmax = absmax if (self.qat_enabled and self.training) else None
+        self.repeat_observation()
+        return out
+
+    def repeat_observation(self):
+        """Advance the running-scale buffers as one more training-mode forward on the same input and
+        weights would (used when a caller reuses the output instead of recomputing it)."""
+        absmax = getattr(self, "_last_absmax", None)
+        if absmax is not None:
             # order of absmax: features, act1, act2, output, W1, W2, W3
             for i, name in enumerate(self.ACT_QUANT + self.WEIGHT_QUANT):
                 getattr(self, name).observe(absmax[i])
-        return out
 
     def get_quantized_weights(self) -> Dict[str, torch.Tensor]:
         weights = {}

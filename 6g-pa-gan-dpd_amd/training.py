@@ -127,10 +127,16 @@ class Stage2Step:
         gen, disc, dp = self.gen, self.disc, self.dp
         info = {}
         d_params = list(disc.parameters())
+        fake = None
         for it in range(self.n_critic):
             self.d_opt.zero_grad(set_to_none=True)
-            with torch.no_grad():
-                fake = gen(iq)
+            if fake is None:
+                with torch.no_grad():
+                    fake = gen(iq)
+            elif hasattr(gen, "repeat_observation"):
+                # the generator does not change during the critic updates: the reference recomputes an
+                # identical forward each time; only its running-scale bookkeeping has to advance
+                gen.repeat_observation()
             alpha = alphas[it] if alphas is not None else None
             d_total, d_info = self._critic_loss(target, fake, cond, alpha)
             d_total.backward()

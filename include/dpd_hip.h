@@ -133,9 +133,11 @@ int dpd_critic_forward(const float *x, const float *cond, int64_t N, const float
 
 /* Backward for an upstream gscore[N] (or, if gscore is NULL, the constant gconst for every row):
  * grads[2945] w.r.t. wb and/or gx [N,2] w.r.t. x (either may be NULL, not both; ws is only needed
- * when grads is requested). */
+ * when grads is requested).  score_sum (optional) receives sum_n score[n] of the recomputed forward, so
+ * a loss that is linear in the scores (the Wasserstein terms, models/discriminator.py:219-226, 259-260)
+ * needs no separate forward call. */
 int dpd_critic_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope,
-                        const float *gscore, float gconst, float *grads, float *gx,
+                        const float *gscore, float gconst, float *grads, float *gx, float *score_sum,
                         void *ws, size_t ws_bytes, void *stream);
 
 /* compute_gradient_penalty (models/discriminator.py:139-191) with its double backward fused:
