@@ -33,7 +33,8 @@ constexpr int SER_STRIDE = 71;      // words between series (71 = 7 mod 32: bank
 constexpr int SER_BASE0 = 5;
 constexpr int ZERO_W = 360;         // 64 words that always hold 0: operand of the padding slots 30, 31
                                     // (their reads add the same tile / sample offsets as real slots)
-constexpr int SER_WORDS = 424;
+constexpr int TG_W = 424;           // 64 x float2: the chunk's target / upstream gradient, sample-major (backward only)
+constexpr int SER_WORDS = 552;
 constexpr int P32 = 48;             // row pitch of the 32-column transposition tiles (16 mod 32)
 constexpr int P16 = 16;
 constexpr int GZ1_W = SER_WORDS;                 // 16 x 48
@@ -65,16 +66,26 @@ struct Lane {
     int lane, j, g;
 };
 
-// Load the chunk's 69 IQ points, derive the five series and park them in LDS.
+// The chunk's 69 IQ points as loaded from HBM: point lane in p[0], point 64 + lane (lanes 0..4) in p[1].
+struct ChunkIQ {
+    float2 p[2];
+};
+DEV void load_chunk_iq(ChunkIQ &c, const float2 *__restrict__ iqrow, int64_t t0, int64_t S, int lane) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        int64_t idx = t0 + lane + 64 * rep;
+        c.p[rep] = make_float2(0.f, 0.f);
+        if ((rep == 0 || lane < 5) && idx < S) c.p[rep] = iqrow[idx];
+    }
+}
+// Derive the five series from the loaded points and park them in LDS.
 template <bool QAT>
-DEV void stage_series(float *ser, const float2 *__restrict__ iqrow, int64_t t0, int64_t S, int lane, float s0) {
+DEV void commit_series(float *ser, const ChunkIQ &c, int lane, float s0) {
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
         int tau = lane + 64 * rep;
         if (rep == 1 && lane >= 5) break;
-        int64_t idx = t0 + tau;
-        float2 v = make_float2(0.f, 0.f);
-        if (idx < S) v = iqrow[idx];
+        float2 v = c.p[rep];
         float e = sqrtf(v.x * v.x + v.y * v.y);
         float e2 = e * e;
         float e4 = e2 * e2;
@@ -92,6 +103,12 @@ DEV void stage_series(float *ser, const float2 *__restrict__ iqrow, int64_t t0, 
         p[3 * SER_STRIDE] = e2;
         p[4 * SER_STRIDE] = e4;
     }
+}
+template <bool QAT>
+DEV void stage_series(float *ser, const float2 *__restrict__ iqrow, int64_t t0, int64_t S, int lane, float s0) {
+    ChunkIQ c;
+    load_chunk_iq(c, iqrow, t0, S, lane);
+    commit_series<QAT>(ser, c, lane, s0);
 }
 
 struct FwdWeights {
@@ -340,28 +357,51 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     float db3[2] = {0.f, 0.f};
     float loss = 0.f;
 
-    for (int64_t chunk = (int64_t)blockIdx.x * WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * WAVES) {
-        const int64_t row = chunk / cpr, t0 = (chunk - row * cpr) * CHUNK;
-        stage_series<QAT>(ser, iq + row * S, t0, S, lane, s0);
-        // upstream gradient source for sample j of tile c: src[16 c]
-        const float2 *src = (MSE ? target : grad_out) + row * L + t0 + j;
+    // The HBM reads of a chunk (69 IQ points, 64 targets or upstream gradients) are issued one chunk
+    // ahead and parked in LDS at the top of the next iteration: no load latency inside the tile code.
+    const float2 *gsrc = MSE ? target : grad_out;
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    int64_t chunk = (int64_t)blockIdx.x * WAVES + wave;
+    ChunkIQ pre;
+    float2 pre_tg = make_float2(0.f, 0.f);
+    int64_t t0 = 0;
+    if (chunk < n_chunks) {
+        const int64_t row = chunk / cpr;
+        t0 = (chunk - row * cpr) * CHUNK;
+        load_chunk_iq(pre, iq + row * S, t0, S, lane);
+        if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
+    }
+    float2 *tg_lds = reinterpret_cast<float2 *>(ser + TG_W);
+    while (chunk < n_chunks) {
+        commit_series<QAT>(ser, pre, lane, s0);
+        tg_lds[lane] = pre_tg;
+        const int64_t t0_cur = t0;
+        chunk += stride;
+        pre_tg = make_float2(0.f, 0.f);
+        if (chunk < n_chunks) {
+            const int64_t row = chunk / cpr;
+            t0 = (chunk - row * cpr) * CHUNK;
+            load_chunk_iq(pre, iq + row * S, t0, S, lane);
+            if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
+        }
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (t0 + 16 * c >= L) break;
+            if (t0_cur + 16 * c >= L) break;
             TileFwd tf;
             tile_forward<QAT, 3>(tf, w, reinterpret_cast<const char *>(ser), boff, c, slope, s1, s2);
-            const bool valid = (t0 + 16 * c + j) < L;
+            const bool valid = (t0_cur + 16 * c + j) < L;
             float g0 = 0.f, g1 = 0.f;
-            if (valid) {
-                const float2 v = src[16 * c];
+            {
+                const float2 v = tg_lds[16 * c + j];
                 if (MSE) {
                     float o0 = QAT ? fq16(tf.y[0], s3) : tf.y[0], o1 = QAT ? fq16(tf.y[1], s3) : tf.y[1];
-                    float d0 = o0 - v.x, d1 = o1 - v.y;
+                    float d0 = valid ? o0 - v.x : 0.f, d1 = valid ? o1 - v.y : 0.f;
                     loss += d0 * d0 + d1 * d1;          // counted in all four lanes of the sample
                     g0 = d0 * mse_scale;
                     g1 = d1 * mse_scale;
                 } else {
-                    g0 = v.x;
+                    g0 = v.x;                           // zero beyond L (never loaded)
                     g1 = v.y;
                 }
             }
