@@ -35,13 +35,15 @@ constexpr int ZERO_W = 360;         // 64 words that always hold 0: operand of t
                                     // (their reads add the same tile / sample offsets as real slots)
 constexpr int TG_W = 424;           // 64 x float2: the chunk's target / upstream gradient, sample-major (backward only)
 constexpr int SER_WORDS = 552;
-constexpr int P32 = 48;             // row pitch of the 32-column transposition tiles (16 mod 32)
-constexpr int P16 = 16;
-constexpr int GZ1_W = SER_WORDS;                 // 16 x 48
-constexpr int H1_W = GZ1_W + 16 * P32;           // 16 x 48
-constexpr int GZ2_W = H1_W + 16 * P32;           // 16 x 16
-constexpr int BWD_WORDS = GZ2_W + 16 * P16;      // 2160 words per wave
+constexpr int P32 = 48;             // row pitch of the transposition tiles (16 mod 32)
+// backward: two tile buffers per wave (two tiles are in flight), each = [16 samples][gz1 (32) | gz2 (16)] and
+// [16 samples][h1 (32) | unused (16)], both with the 48-word pitch and the XOR swizzle of swz()
+constexpr int TILE_W = 2 * 16 * P32;             // words per tile buffer (1536)
+constexpr int GZ_W = SER_WORDS;                  // + TILE_W * buffer
+constexpr int H1_W = GZ_W + 16 * P32;
+constexpr int BWD_WORDS = SER_WORDS + 2 * TILE_W;   // 3624 words per wave
 static_assert(WAVES * BWD_WORDS >= WAVES * G_SLAB, "the gradient rows are combined in the staging LDS");
+static_assert(WAVES * BWD_WORDS * 4 <= 65536, "static LDS limit");
 
 DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -323,19 +325,15 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         int slot = 16 * u + j;
         aoff[u] = 4 * (slot_word(slot) + (slot < 30 ? g : 0));
     }
-    // transposition tiles: write addresses (row j) and read addresses (row 4q + g)
+    // transposition tiles: write address (row j) and read addresses (row 4q + g)
     const int wr32 = 4 * (j * P32 + ((4 * g) ^ swz(j)));
-    const int wr16 = 4 * (j * P16 + ((4 * g) ^ swz(j)));
-    int rd32[4], rd16[4];
+    int rd32[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         int s = 4 * q + g;
         rd32[q] = 4 * (s * P32 + (j ^ swz(s)));
-        rd16[q] = 4 * (s * P16 + (j ^ swz(s)));
     }
-    char *gz1_b = reinterpret_cast<char *>(ser + GZ1_W);
-    char *h1_b = reinterpret_cast<char *>(ser + H1_W);
-    char *gz2_b = reinterpret_cast<char *>(ser + GZ2_W);
+    char *const ser_b = reinterpret_cast<char *>(ser);
 
     float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
     if (QAT) {
@@ -356,105 +354,220 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     f32x4 db2 = {0.f, 0.f, 0.f, 0.f};
     float db3[2] = {0.f, 0.f};
     float loss = 0.f;
+    const bool odd = (g & 1) != 0;
+    float2 *const tg_lds = reinterpret_cast<float2 *>(ser + TG_W);
+
+    // One tile's life is a strict alternation of MFMA stages (S1 FC1, S2 FC2, S3 FC3, S4 gh2, S5 gh1,
+    // S6 weight-gradient outer products) and VALU/LDS stages (V1..V5) that each need the previous MFMA
+    // result.  Two tiles (A, B) of the chunk run half a stage apart in one instruction stream, so the
+    // VALU stage of one tile sits in the shadow of the other tile's MFMAs:
+    //   S1A | S1B+V1A | S2A+V1B | S2B+V2A | S3A+V2B | S3B+V3A | S4A+V3B | S4B+V4A | S5A+V4B | S5B+V5A | S6A+V5B | S6B
+    struct Tile {
+        f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, z3, gz2, e0, e1;
+        float gsel;
+    };
+    auto S1 = [&](Tile &t, int c) {
+        t.a0 = w.bias1[0];
+        t.a1 = w.bias1[1];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            float b = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
+            t.a0 = mfma4(w.A1[0][s], b, t.a0);
+            t.a1 = mfma4(w.A1[1][s], b, t.a1);
+        }
+    };
+    auto V1 = [&](Tile &t, int buf) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t.m1a[r] = t.a0[r] > 0.f ? 1.f : slope;
+            t.m1b[r] = t.a1[r] > 0.f ? 1.f : slope;
+        }
+        t.a0 *= t.m1a;
+        t.a1 *= t.m1b;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t.ha[r] = QAT ? fq16(t.a0[r], s1) : t.a0[r];
+            t.hb[r] = QAT ? fq16(t.a1[r], s1) : t.a1[r];
+        }
+        char *h1_b = ser_b + 4 * (H1_W + TILE_W * buf);
+        *reinterpret_cast<f32x4 *>(h1_b + wr32) = t.ha;
+        *reinterpret_cast<f32x4 *>(h1_b + wr32 + 64) = t.hb;
+    };
+    auto S2 = [&](Tile &t) {
+        t.c0 = w.bias2;
+        t.c1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t.c0 = mfma4(w.A2[0][r], t.ha[r], t.c0);
+            t.c1 = mfma4(w.A2[1][r], t.hb[r], t.c1);
+        }
+    };
+    auto V2 = [&](Tile &t) {
+        t.c0 += t.c1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.m2[r] = t.c0[r] > 0.f ? 1.f : slope;
+        t.c0 *= t.m2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.h2[r] = QAT ? fq16(t.c0[r], s2) : t.c0[r];
+    };
+    auto S3 = [&](Tile &t) {
+        t.z3 = w.bias3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.z3 = mfma4(w.A3[r], t.h2[r], t.z3);
+    };
+    auto V3 = [&](Tile &t, int c, int64_t t0_cur) {
+        // each lane evaluates one tanh (output g & 1) and fetches the other from lane ^ 16
+        const float mine = tanh_f32(odd ? t.z3[1] : t.z3[0]);
+        const float other = swap16(mine);
+        const float y0 = odd ? other : mine, y1 = odd ? mine : other;
+        const bool valid = (t0_cur + 16 * c + j) < L;
+        const float2 v = tg_lds[16 * c + j];
+        float g0, g1;
+        if (MSE) {
+            float o0 = QAT ? fq16(y0, s3) : y0, o1 = QAT ? fq16(y1, s3) : y1;
+            float d0 = valid ? o0 - v.x : 0.f, d1 = valid ? o1 - v.y : 0.f;
+            loss += d0 * d0 + d1 * d1;          // counted in all four lanes of the sample
+            g0 = d0 * mse_scale;
+            g1 = d1 * mse_scale;
+        } else {
+            g0 = v.x;                           // zero beyond L (never loaded)
+            g1 = v.y;
+        }
+        const float gz3_0 = g0 * (1.f - y0 * y0), gz3_1 = g1 * (1.f - y1 * y1);
+        db3[0] += gz3_0;                        // identical in the four lane groups; group 0 is stored
+        db3[1] += gz3_1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dW3[0][r] = __builtin_fmaf(gz3_0, t.h2[r], dW3[0][r]);
+            dW3[1][r] = __builtin_fmaf(gz3_1, t.h2[r], dW3[1][r]);
+        }
+        t.gsel = odd ? gz3_1 : gz3_0;
+    };
+    // gh2^T = W3^T gz3^T: one MFMA with k = output index on the lane groups (groups 2, 3 multiply zeros)
+    auto S4 = [&](Tile &t) { t.gz2 = mfma4(A3T, t.gsel, f32x4{0.f, 0.f, 0.f, 0.f}); };
+    auto V4 = [&](Tile &t, int buf) {
+        t.gz2 *= t.m2;
+        db2 += t.gz2;
+        *reinterpret_cast<f32x4 *>(ser_b + 4 * (GZ_W + TILE_W * buf) + wr32 + 128) = t.gz2;
+    };
+    auto S5 = [&](Tile &t) {   // gh1^T = W2^T gz2^T  (two row tiles of 16 h1-neurons)
+        t.e0 = f32x4{0.f, 0.f, 0.f, 0.f};
+        t.e1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            t.e0 = mfma4(A2T[0][r], t.gz2[r], t.e0);
+            t.e1 = mfma4(A2T[1][r], t.gz2[r], t.e1);
+        }
+    };
+    auto V5 = [&](Tile &t, int buf) {
+        t.e0 *= t.m1a;
+        t.e1 *= t.m1b;
+        db1[0] += t.e0;
+        db1[1] += t.e1;
+        char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
+        *reinterpret_cast<f32x4 *>(gz_b + wr32) = t.e0;
+        *reinterpret_cast<f32x4 *>(gz_b + wr32 + 64) = t.e1;
+    };
+    auto S6 = [&](int c, int buf) {   // samples move from lanes to the MFMA K axis through the LDS tiles
+        const char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
+        const char *h1_b = ser_b + 4 * (H1_W + TILE_W * buf);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // samples 4q + g of this tile
+            float x0 = *reinterpret_cast<const float *>(ser_b + aoff[0] + 64 * c + 16 * q);
+            float x1 = *reinterpret_cast<const float *>(ser_b + aoff[1] + 64 * c + 16 * q);
+            float gza = *reinterpret_cast<const float *>(gz_b + rd32[q]);
+            float gzb = *reinterpret_cast<const float *>(gz_b + rd32[q] + 64);
+            dW1[0][0] = mfma4(x0, gza, dW1[0][0]);
+            dW1[0][1] = mfma4(x0, gzb, dW1[0][1]);
+            dW1[1][0] = mfma4(x1, gza, dW1[1][0]);
+            dW1[1][1] = mfma4(x1, gzb, dW1[1][1]);
+            float ha = *reinterpret_cast<const float *>(h1_b + rd32[q]);
+            float hb = *reinterpret_cast<const float *>(h1_b + rd32[q] + 64);
+            float g2 = *reinterpret_cast<const float *>(gz_b + rd32[q] + 128);
+            dW2[0] = mfma4(ha, g2, dW2[0]);
+            dW2[1] = mfma4(hb, g2, dW2[1]);
+        }
+    };
+#define PHASE() __builtin_amdgcn_sched_barrier(0)
 
     // The HBM reads of a chunk (69 IQ points, 64 targets or upstream gradients) are issued one chunk
     // ahead and parked in LDS at the top of the next iteration: no load latency inside the tile code.
     const float2 *gsrc = MSE ? target : grad_out;
     const int64_t stride = (int64_t)gridDim.x * WAVES;
     int64_t chunk = (int64_t)blockIdx.x * WAVES + wave;
+    // (row, position in row) of the chunk advance by a fixed step: one division at kernel start only
+    const int64_t step_rows = stride / cpr, step_pos = stride - step_rows * cpr;
+    int64_t row = chunk / cpr, pos = chunk - row * cpr;
     ChunkIQ pre;
     float2 pre_tg = make_float2(0.f, 0.f);
     int64_t t0 = 0;
     if (chunk < n_chunks) {
-        const int64_t row = chunk / cpr;
-        t0 = (chunk - row * cpr) * CHUNK;
+        t0 = pos * CHUNK;
         load_chunk_iq(pre, iq + row * S, t0, S, lane);
         if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
     }
-    float2 *tg_lds = reinterpret_cast<float2 *>(ser + TG_W);
     while (chunk < n_chunks) {
         commit_series<QAT>(ser, pre, lane, s0);
         tg_lds[lane] = pre_tg;
         const int64_t t0_cur = t0;
         chunk += stride;
+        row += step_rows;
+        pos += step_pos;
+        if (pos >= cpr) {
+            pos -= cpr;
+            ++row;
+        }
         pre_tg = make_float2(0.f, 0.f);
         if (chunk < n_chunks) {
-            const int64_t row = chunk / cpr;
-            t0 = (chunk - row * cpr) * CHUNK;
+            t0 = pos * CHUNK;
             load_chunk_iq(pre, iq + row * S, t0, S, lane);
             if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            if (t0_cur + 16 * c >= L) break;
-            TileFwd tf;
-            tile_forward<QAT, 3>(tf, w, reinterpret_cast<const char *>(ser), boff, c, slope, s1, s2);
-            const bool valid = (t0_cur + 16 * c + j) < L;
-            float g0 = 0.f, g1 = 0.f;
-            {
-                const float2 v = tg_lds[16 * c + j];
-                if (MSE) {
-                    float o0 = QAT ? fq16(tf.y[0], s3) : tf.y[0], o1 = QAT ? fq16(tf.y[1], s3) : tf.y[1];
-                    float d0 = valid ? o0 - v.x : 0.f, d1 = valid ? o1 - v.y : 0.f;
-                    loss += d0 * d0 + d1 * d1;          // counted in all four lanes of the sample
-                    g0 = d0 * mse_scale;
-                    g1 = d1 * mse_scale;
-                } else {
-                    g0 = v.x;                           // zero beyond L (never loaded)
-                    g1 = v.y;
-                }
-            }
-            const float gz3_0 = g0 * (1.f - tf.y[0] * tf.y[0]), gz3_1 = g1 * (1.f - tf.y[1] * tf.y[1]);
-            db3[0] += gz3_0;                            // identical in the four lane groups; group 0 is stored
-            db3[1] += gz3_1;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                dW3[0][r] = __builtin_fmaf(gz3_0, tf.h2[r], dW3[0][r]);
-                dW3[1][r] = __builtin_fmaf(gz3_1, tf.h2[r], dW3[1][r]);
-            }
-            // gh2^T = W3^T gz3^T: one MFMA with k = output index on the lane groups (groups 2, 3 multiply zeros)
-            f32x4 gz2 = mfma4(A3T, (g & 1) ? gz3_1 : gz3_0, f32x4{0.f, 0.f, 0.f, 0.f});
-            gz2 *= tf.m2;
-            db2 += gz2;
-            // gh1^T = W2^T gz2^T  (two row tiles of 16 h1-neurons)
-            f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                e0 = mfma4(A2T[0][r], gz2[r], e0);
-                e1 = mfma4(A2T[1][r], gz2[r], e1);
-            }
-            f32x4 gz1[2] = {e0 * tf.m1[0], e1 * tf.m1[1]};
-            db1[0] += gz1[0];
-            db1[1] += gz1[1];
-            // lanes -> K axis: park [sample][neuron] tiles in LDS
-            *reinterpret_cast<f32x4 *>(gz1_b + wr32) = gz1[0];
-            *reinterpret_cast<f32x4 *>(gz1_b + wr32 + 64) = gz1[1];
-            *reinterpret_cast<f32x4 *>(h1_b + wr32) = tf.h1[0];
-            *reinterpret_cast<f32x4 *>(h1_b + wr32 + 64) = tf.h1[1];
-            *reinterpret_cast<f32x4 *>(gz2_b + wr16) = gz2;
-            __builtin_amdgcn_wave_barrier();
-            const char *ser_b = reinterpret_cast<const char *>(ser);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                // samples 4q + g of this tile
-                float x0 = *reinterpret_cast<const float *>(ser_b + aoff[0] + 64 * c + 16 * q);
-                float x1 = *reinterpret_cast<const float *>(ser_b + aoff[1] + 64 * c + 16 * q);
-                float gza = *reinterpret_cast<const float *>(gz1_b + rd32[q]);
-                float gzb = *reinterpret_cast<const float *>(gz1_b + rd32[q] + 64);
-                dW1[0][0] = mfma4(x0, gza, dW1[0][0]);
-                dW1[0][1] = mfma4(x0, gzb, dW1[0][1]);
-                dW1[1][0] = mfma4(x1, gza, dW1[1][0]);
-                dW1[1][1] = mfma4(x1, gzb, dW1[1][1]);
-                float ha = *reinterpret_cast<const float *>(h1_b + rd32[q]);
-                float hb = *reinterpret_cast<const float *>(h1_b + rd32[q] + 64);
-                float g2 = *reinterpret_cast<const float *>(gz2_b + rd16[q]);
-                dW2[0] = mfma4(ha, g2, dW2[0]);
-                dW2[1] = mfma4(hb, g2, dW2[1]);
-            }
-            __builtin_amdgcn_wave_barrier();
+        for (int p = 0; p < 2; ++p) {
+            // tiles beyond L inside a started pair run with zero upstream gradient: they add nothing
+            if (t0_cur + 32 * p >= L) break;
+            const int cA = 2 * p, cB = 2 * p + 1;
+            Tile A, B;
+            S1(A, cA);
+            PHASE();
+            S1(B, cB);
+            V1(A, 0);
+            PHASE();
+            S2(A);
+            V1(B, 1);
+            PHASE();
+            S2(B);
+            V2(A);
+            PHASE();
+            S3(A);
+            V2(B);
+            PHASE();
+            S3(B);
+            V3(A, cA, t0_cur);
+            PHASE();
+            S4(A);
+            V3(B, cB, t0_cur);
+            PHASE();
+            S4(B);
+            V4(A, 0);
+            PHASE();
+            S5(A);
+            V4(B, 1);
+            PHASE();
+            S5(B);
+            V5(A, 0);
+            PHASE();
+            S6(cA, 0);
+            V5(B, 1);
+            PHASE();
+            S6(cB, 1);
+            PHASE();
         }
     }
+#undef PHASE
 
     // ---- partial gradient row of this wave -> LDS, the workgroup's four rows are summed, one row per
     // workgroup goes to the slab (the staging regions are dead: every wave has left its loop)
