@@ -299,7 +299,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
                                                              const float *__restrict__ absmax,
                                                              const float2 *__restrict__ grad_out,
                                                              const float2 *__restrict__ target, float mse_scale,
-                                                             float *__restrict__ slab) {
+                                                             float *__restrict__ slab, unsigned *__restrict__ queue) {
     __shared__ __attribute__((aligned(16))) float lds[WAVES][BWD_WORDS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     float *ser = lds[wave];
@@ -494,33 +494,41 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // The HBM reads of a chunk (69 IQ points, 64 targets or upstream gradients) are issued one chunk
     // ahead and parked in LDS at the top of the next iteration: no load latency inside the tile code.
     const float2 *gsrc = MSE ? target : grad_out;
-    const int64_t stride = (int64_t)gridDim.x * WAVES;
-    int64_t chunk = (int64_t)blockIdx.x * WAVES + wave;
-    // (row, position in row) of the chunk advance by a fixed step: one division at kernel start only
-    const int64_t step_rows = stride / cpr, step_pos = stride - step_rows * cpr;
-    int64_t row = chunk / cpr, pos = chunk - row * cpr;
+    // Units of UNIT consecutive chunks are handed out through a device counter (first come, first
+    // served): waves on faster or earlier-started CUs take more units, none idles at the end.  The
+    // counter is read one unit ahead, so its latency stays hidden.  n_chunks < 2^31 (checked on the host).
+    constexpr unsigned UNIT = 4;
+    const unsigned n_waves = gridDim.x * WAVES, cpr32 = (unsigned)cpr, n_chunks32 = (unsigned)n_chunks;
+    auto take = [&]() -> unsigned {
+        unsigned v = 0;
+        if (lane == 0) v = atomicAdd(queue, 1u);
+        return n_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    };
+    unsigned unit = blockIdx.x * WAVES + wave, next_unit = take(), in_unit = 0;
+    unsigned chunk = unit * UNIT;
     ChunkIQ pre;
     float2 pre_tg = make_float2(0.f, 0.f);
     int64_t t0 = 0;
-    if (chunk < n_chunks) {
-        t0 = pos * CHUNK;
+    if (chunk < n_chunks32) {
+        const unsigned row = chunk / cpr32;
+        t0 = (int64_t)(chunk - row * cpr32) * CHUNK;
         load_chunk_iq(pre, iq + row * S, t0, S, lane);
         if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
     }
-    while (chunk < n_chunks) {
+    while (chunk < n_chunks32) {
         commit_series<QAT>(ser, pre, lane, s0);
         tg_lds[lane] = pre_tg;
         const int64_t t0_cur = t0;
-        chunk += stride;
-        row += step_rows;
-        pos += step_pos;
-        if (pos >= cpr) {
-            pos -= cpr;
-            ++row;
+        if (++in_unit == UNIT) {
+            in_unit = 0;
+            unit = next_unit;
+            next_unit = take();
         }
+        chunk = unit * UNIT + in_unit;
         pre_tg = make_float2(0.f, 0.f);
-        if (chunk < n_chunks) {
-            t0 = pos * CHUNK;
+        if (chunk < n_chunks32) {
+            const unsigned row = chunk / cpr32;
+            t0 = (int64_t)(chunk - row * cpr32) * CHUNK;
             load_chunk_iq(pre, iq + row * S, t0, S, lane);
             if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
         }
@@ -658,14 +666,19 @@ int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *t
                       hipStream_t st) {
     const float2 *iq = reinterpret_cast<const float2 *>(p.x);
     const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
+    DPD_REQUIRE(n_chunks < ((int64_t)1 << 31) - 4096 && p.S < ((int64_t)1 << 31), DPD_ERR_SHAPE,
+                "gen_backward: %lld chunks of 64 samples exceed the 32-bit chunk counter", (long long)n_chunks);
     const int gridn = mfma_grid(n_chunks, BWD_WAVES_PER_SIMD);
     *n_partials = gridn;
+    // chunk counter: one word behind the largest slab this call can write (the workspace is far larger)
+    unsigned *queue = reinterpret_cast<unsigned *>(slab + (size_t)1024 * G_SLAB);
+    DPD_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
     const dim3 grid(gridn), block(WAVES * 64);
     const bool mse = grad_out == nullptr;
     const float mse_scale = mse ? (float)(2.0 / (2.0 * (double)p.N)) : 0.f;
     const float2 *go = reinterpret_cast<const float2 *>(grad_out), *tg = reinterpret_cast<const float2 *>(target);
 #define GO(Q, M) hipLaunchKernelGGL((k_gen_bwd_mfma<Q, M>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
-                                    p.slope, p.absmax, go, tg, mse_scale, slab)
+                                    p.slope, p.absmax, go, tg, mse_scale, slab, queue)
     if (p.qat) { if (mse) GO(true, true); else GO(true, false); }
     else       { if (mse) GO(false, true); else GO(false, false); }
 #undef GO
