@@ -6,7 +6,7 @@ import threading
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpd_hip.so")
+LIB_PATH = os.environ.get("DPD_HIP_LIBRARY") or os.path.join(_HERE, "libdpd_hip.so")   # override: another build of the same ABI
 
 GEN_NPARAM = 1554
 GEN_NSCALE = 8

@@ -7,6 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdpd_hip.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+EXTRA = os.environ.get("DPD_EXTRA_FLAGS", "").split()   # experiments only, e.g. -DBWD_WAVES_PER_SIMD=1
 # -ffp-contract=off: the reference computes I*I + Q*Q and friends with separate roundings; fused
 # multiply-adds are written explicitly where they are wanted.
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs; the kernels consume them on the VALU right
@@ -36,7 +37,7 @@ def build(force=False, verbose=True, jobs=8):
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA + ["-c", src, "-o", obj]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x"); cmd.insert(2, "hip")
         if verbose:

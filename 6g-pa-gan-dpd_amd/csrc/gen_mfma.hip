@@ -31,17 +31,19 @@ constexpr int WAVES = 4;
 constexpr int CHUNK = 64;           // samples per wave iteration
 constexpr int SER_STRIDE = 71;      // words between series (71 = 7 mod 32: bank-disjoint operand reads)
 constexpr int SER_BASE0 = 5;
-constexpr int ZERO_W = 360;         // 64 words that always hold 0: operand of the padding slots 30, 31
+constexpr int ZERO_W = 360;         // 64 words that always hold 0: operand of the padding slot 31
                                     // (their reads add the same tile / sample offsets as real slots)
-constexpr int TG_W = 424;           // 64 x float2: the chunk's target / upstream gradient, sample-major (backward only)
-constexpr int SER_WORDS = 552;
+constexpr int ONE_W = 424;          // 64 words that always hold 1: slot 30 is the bias input (its W1 column is b1,
+                                    // its dW1 row is the bias gradient)
+constexpr int TG_W = 488;           // 64 x float2: the chunk's target / upstream gradient, sample-major (backward only)
+constexpr int SER_WORDS = 616;
 constexpr int P32 = 48;             // row pitch of the transposition tiles (16 mod 32)
 // backward: two tile buffers per wave (two tiles are in flight), each = [16 samples][gz1 (32) | gz2 (16)] and
 // [16 samples][h1 (32) | unused (16)], both with the 48-word pitch and the XOR swizzle of swz()
 constexpr int TILE_W = 2 * 16 * P32;             // words per tile buffer (1536)
 constexpr int GZ_W = SER_WORDS;                  // + TILE_W * buffer
 constexpr int H1_W = GZ_W + 16 * P32;
-constexpr int BWD_WORDS = SER_WORDS + 2 * TILE_W;   // 3624 words per wave
+constexpr int BWD_WORDS = SER_WORDS + 2 * TILE_W;   // 3688 words per wave
 static_assert(WAVES * BWD_WORDS >= WAVES * G_SLAB, "the gradient rows are combined in the staging LDS");
 static_assert(WAVES * BWD_WORDS * 4 <= 65536, "static LDS limit");
 
@@ -57,7 +59,7 @@ DEV int slot_ref(int slot) {
 }
 // word offset inside the series region of (slot, sample 0 of tile 0); add sample index and 16 * tile
 DEV int slot_word(int slot) {
-    if (slot >= 30) return ZERO_W;
+    if (slot >= 30) return slot == 30 ? ONE_W : ZERO_W;
     int type = slot / 6, tap = slot - 6 * type;
     return SER_BASE0 + SER_STRIDE * type + 5 - tap;
 }
@@ -118,7 +120,6 @@ struct FwdWeights {
     float A2[2][4];   // W2[i][16t + 4g + r]
     float A3[4];      // W3 with its two rows repeated at rows 4q, 4q+1 of a 16-row tile: every lane
                       // group then finds z3_0, z3_1 in registers 0, 1 of the result (no cross-lane sum)
-    f32x4 bias1[2];   // b1[16t + 4g + r]
     f32x4 bias2;      // b2[4g + r]
     f32x4 bias3;      // (b3_0, b3_1, 0, 0)
 };
@@ -129,7 +130,7 @@ DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, in
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             int ref = slot_ref(4 * s + g);
-            w.A1[t][s] = ref >= 0 ? wq[G_W1 + (16 * t + j) * 30 + ref] : 0.f;
+            w.A1[t][s] = ref >= 0 ? wq[G_W1 + (16 * t + j) * 30 + ref] : (4 * s + g == 30 ? wq[G_B1 + 16 * t + j] : 0.f);
         }
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -137,10 +138,6 @@ DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, in
         for (int r = 0; r < 4; ++r) w.A2[t][r] = wq[G_W2 + j * 32 + 16 * t + 4 * g + r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) w.A3[r] = (j & 3) < 2 ? wq[G_W3 + (j & 3) * 16 + 4 * g + r] : 0.f;
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w.bias1[t][r] = wq[G_B1 + 16 * t + 4 * g + r];
 #pragma unroll
     for (int r = 0; r < 4; ++r) w.bias2[r] = wq[G_B2 + 4 * g + r];
     w.bias3 = f32x4{wq[G_B3], wq[G_B3 + 1], 0.f, 0.f};
@@ -174,7 +171,7 @@ DEV float swap16(float v) {   // value of lane ^ 16 (ds_swizzle bit mode: and 0x
 template <bool QAT, int DEPTH>
 DEV void tile_forward(TileFwd &tf, const FwdWeights &w, const char *ser_bytes, const int (&boff)[8], int tile,
                       float slope, float s1, float s2) {
-    f32x4 a0 = w.bias1[0], a1 = w.bias1[1];
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         float b = *reinterpret_cast<const float *>(ser_bytes + boff[s] + 64 * tile);
@@ -227,6 +224,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_fwd_mfma(const float2 *__res
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     float *ser = lds[wave];
     ser[ZERO_W + lane] = 0.f;
+    ser[ONE_W + lane] = 1.f;
     FwdWeights w;
     load_fwd_weights(w, wq, j, g);
     int boff[8];
@@ -304,6 +302,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     float *ser = lds[wave];
     ser[ZERO_W + lane] = 0.f;
+    ser[ONE_W + lane] = 1.f;
     FwdWeights w;
     load_fwd_weights(w, wq, j, g);
     float A2T[2][4];  // W2[4g + r][16t + i]
@@ -350,12 +349,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         for (int t = 0; t < 2; ++t) dW1[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     float dW3[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-    f32x4 db1[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 db2 = {0.f, 0.f, 0.f, 0.f};
-    float db3[2] = {0.f, 0.f};
+    float db3 = 0.f;
     float loss = 0.f;
     const bool odd = (g & 1) != 0;
     float2 *const tg_lds = reinterpret_cast<float2 *>(ser + TG_W);
+    const float *const tg_f = ser + TG_W;
 
     // One tile's life is a strict alternation of MFMA stages (S1 FC1, S2 FC2, S3 FC3, S4 gh2, S5 gh1,
     // S6 weight-gradient outer products) and VALU/LDS stages (V1..V5) that each need the previous MFMA
@@ -366,14 +365,18 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, z3, gz2, e0, e1;
         float gsel;
     };
-    auto S1 = [&](Tile &t, int c) {
-        t.a0 = w.bias1[0];
-        t.a1 = w.bias1[1];
+    // FC1 operands are fetched from LDS one stage before the MFMAs that use them
+    auto F1 = [&](float (&b)[8], int c) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
+    };
+    auto S1 = [&](Tile &t, const float (&b)[8]) {
+        t.a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
+        t.a1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            float b = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
-            t.a0 = mfma4(w.A1[0][s], b, t.a0);
-            t.a1 = mfma4(w.A1[1][s], b, t.a1);
+            t.a0 = mfma4(w.A1[0][s], b[s], t.a0);
+            t.a1 = mfma4(w.A1[1][s], b[s], t.a1);
         }
     };
     auto V1 = [&](Tile &t, int buf) {
@@ -415,33 +418,50 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #pragma unroll
         for (int r = 0; r < 4; ++r) t.z3 = mfma4(w.A3[r], t.h2[r], t.z3);
     };
-    auto V3 = [&](Tile &t, int c, int64_t t0_cur) {
-        // each lane evaluates one tanh (output g & 1) and fetches the other from lane ^ 16
-        const float mine = tanh_f32(odd ? t.z3[1] : t.z3[0]);
-        const float other = swap16(mine);
-        const float y0 = odd ? other : mine, y1 = odd ? mine : other;
-        const bool valid = (t0_cur + 16 * c + j) < L;
-        const float2 v = tg_lds[16 * c + j];
-        float g0, g1;
+    // Output stage of a tile pair: 32 samples x 2 outputs = one (sample, output) per lane.  Lane (g, j)
+    // takes output g & 1 of sample j of tile g >> 1 (every lane group holds z3 of its own sample j), so
+    // tanh, loss and gz3 are evaluated once each; gz3 then goes to all lane groups with three row swaps.
+    const int tg_off = 2 * (16 * (g >> 1) + j) + (g & 1);
+    auto V3P = [&](Tile &A, Tile &B, int p, int64_t t0_cur) {
+        const float zA = odd ? A.z3[1] : A.z3[0], zB = odd ? B.z3[1] : B.z3[0];
+#ifdef ABL_NO_TANH
+        const float y = g >= 2 ? zB : zA;
+#else
+        const float y = tanh_f32(g >= 2 ? zB : zA);
+#endif
+        const bool valid = (t0_cur + 32 * p + 16 * (g >> 1) + j) < L;
+        const float v = tg_f[tg_off + 64 * p];
+        float gup;
         if (MSE) {
-            float o0 = QAT ? fq16(y0, s3) : y0, o1 = QAT ? fq16(y1, s3) : y1;
-            float d0 = valid ? o0 - v.x : 0.f, d1 = valid ? o1 - v.y : 0.f;
-            loss += d0 * d0 + d1 * d1;          // counted in all four lanes of the sample
-            g0 = d0 * mse_scale;
-            g1 = d1 * mse_scale;
+            const float o = QAT ? fq16(y, s3) : y;
+            const float d = valid ? o - v : 0.f;
+            loss = __builtin_fmaf(d, d, loss);
+            gup = d * mse_scale;
         } else {
-            g0 = v.x;                           // zero beyond L (never loaded)
-            g1 = v.y;
+            gup = v;                            // zero beyond L (never loaded)
         }
-        const float gz3_0 = g0 * (1.f - y0 * y0), gz3_1 = g1 * (1.f - y1 * y1);
-        db3[0] += gz3_0;                        // identical in the four lane groups; group 0 is stored
-        db3[1] += gz3_1;
+        const float gz3 = gup * (1.f - y * y);
+        db3 += gz3;                             // lanes with g & 1 == k collect db3[k]
+        // each swap exchanges rows between its two operands.  The four results pass through an empty asm:
+        // without it this compiler folds the second result of a swap into the first once they are
+        // reinterpreted as floats (observed on ROCm 7.2: b0 == a0, b1 == a1)
+        const unsigned bits = __builtin_bit_cast(unsigned, gz3);
+        const auto r = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);      // rows (0,0,2,2), (1,1,3,3)
+        const auto q0 = __builtin_amdgcn_permlane32_swap(r[0], r[0], false, false);     // row 0 | row 2 everywhere
+        const auto q1 = __builtin_amdgcn_permlane32_swap(r[1], r[1], false, false);     // row 1 | row 3 everywhere
+        unsigned ua0 = q0[0], ub0 = q0[1], ua1 = q1[0], ub1 = q1[1];
+        asm volatile("" : "+v"(ua0), "+v"(ub0), "+v"(ua1), "+v"(ub1));
+        const float a0 = __builtin_bit_cast(float, ua0), b0 = __builtin_bit_cast(float, ub0);
+        const float a1 = __builtin_bit_cast(float, ua1), b1 = __builtin_bit_cast(float, ub1);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            dW3[0][r] = __builtin_fmaf(gz3_0, t.h2[r], dW3[0][r]);
-            dW3[1][r] = __builtin_fmaf(gz3_1, t.h2[r], dW3[1][r]);
+        for (int r4 = 0; r4 < 4; ++r4) {
+            dW3[0][r4] = __builtin_fmaf(a0, A.h2[r4], dW3[0][r4]);
+            dW3[1][r4] = __builtin_fmaf(a1, A.h2[r4], dW3[1][r4]);
+            dW3[0][r4] = __builtin_fmaf(b0, B.h2[r4], dW3[0][r4]);
+            dW3[1][r4] = __builtin_fmaf(b1, B.h2[r4], dW3[1][r4]);
         }
-        t.gsel = odd ? gz3_1 : gz3_0;
+        A.gsel = odd ? a1 : a0;
+        B.gsel = odd ? b1 : b0;
     };
     // gh2^T = W3^T gz3^T: one MFMA with k = output index on the lane groups (groups 2, 3 multiply zeros)
     auto S4 = [&](Tile &t) { t.gz2 = mfma4(A3T, t.gsel, f32x4{0.f, 0.f, 0.f, 0.f}); };
@@ -462,13 +482,14 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     auto V5 = [&](Tile &t, int buf) {
         t.e0 *= t.m1a;
         t.e1 *= t.m1b;
-        db1[0] += t.e0;
-        db1[1] += t.e1;
         char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
         *reinterpret_cast<f32x4 *>(gz_b + wr32) = t.e0;
         *reinterpret_cast<f32x4 *>(gz_b + wr32 + 64) = t.e1;
     };
     auto S6 = [&](int c, int buf) {   // samples move from lanes to the MFMA K axis through the LDS tiles
+#ifdef ABL_NO_S6
+        return;
+#endif
         const char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
         const char *h1_b = ser_b + 4 * (H1_W + TILE_W * buf);
 #pragma unroll
@@ -489,7 +510,11 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             dW2[1] = mfma4(hb, g2, dW2[1]);
         }
     };
+#ifdef ABL_NO_PHASE
+#define PHASE()
+#else
 #define PHASE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
     // The HBM reads of a chunk (69 IQ points, 64 targets or upstream gradients) are issued one chunk
     // ahead and parked in LDS at the top of the next iteration: no load latency inside the tile code.
@@ -539,9 +564,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             if (t0_cur + 32 * p >= L) break;
             const int cA = 2 * p, cB = 2 * p + 1;
             Tile A, B;
-            S1(A, cA);
+            float bA[8], bB[8];
+            F1(bA, cA);
+            F1(bB, cB);
             PHASE();
-            S1(B, cB);
+            S1(A, bA);
+            PHASE();
+            S1(B, bB);
             V1(A, 0);
             PHASE();
             S2(A);
@@ -554,11 +583,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             V2(B);
             PHASE();
             S3(B);
-            V3(A, cA, t0_cur);
+            PHASE();
+            V3P(A, B, p, t0_cur);
             PHASE();
             S4(A);
-            V3(B, cB, t0_cur);
-            PHASE();
             S4(B);
             V4(A, 0);
             PHASE();
@@ -588,8 +616,9 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int ref = slot_ref(16 * u + 4 * g + r);
+                int slot = 16 * u + 4 * g + r, ref = slot_ref(slot);
                 if (ref >= 0) rowp[G_W1 + (16 * t + j) * 30 + ref] = dW1[u][t][r];
+                else if (slot == 30) rowp[G_B1 + 16 * t + j] = dW1[u][t][r];   // sum over samples of 1 * gz1
             }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -602,28 +631,21 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         for (int r = 0; r < 4; ++r) {
             dW3[0][r] += __shfl_xor(dW3[0][r], off);
             dW3[1][r] += __shfl_xor(dW3[1][r], off);
-            db1[0][r] += __shfl_xor(db1[0][r], off);
-            db1[1][r] += __shfl_xor(db1[1][r], off);
             db2[r] += __shfl_xor(db2[r], off);
         }
-        db3[0] += __shfl_xor(db3[0], off);
-        db3[1] += __shfl_xor(db3[1], off);
+        db3 += __shfl_xor(db3, off);
     }
+    db3 += __shfl_xor(db3, 32);                 // lane groups g and g ^ 2 hold the same output index
     if (j == 0) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             rowp[G_W3 + 4 * g + r] = dW3[0][r];
             rowp[G_W3 + 16 + 4 * g + r] = dW3[1][r];
-            rowp[G_B1 + 4 * g + r] = db1[0][r];
-            rowp[G_B1 + 16 + 4 * g + r] = db1[1][r];
             rowp[G_B2 + 4 * g + r] = db2[r];
         }
-        if (g == 0) {
-            rowp[G_B3] = db3[0];
-            rowp[G_B3 + 1] = db3[1];
-        }
+        if (g < 2) rowp[G_B3 + g] = db3;
     }
-    loss = wave_sum(loss) * 0.25f;
+    loss = wave_sum(loss);
     if (lane == 0) rowp[G_NP] = loss;
     __syncthreads();
     float *out_row = slab + (int64_t)blockIdx.x * G_SLAB;
