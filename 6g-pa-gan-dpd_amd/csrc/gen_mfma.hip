@@ -510,8 +510,19 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             dW2[1] = mfma4(hb, g2, dW2[1]);
         }
     };
-#ifdef ABL_NO_PHASE
-#define PHASE()
+#ifdef ABL_TIMING
+    // experiment: cycles between phase boundaries, summed per wave and added into queue[16 + k]
+    unsigned long long tacc[20] = {0}, tlast = __builtin_readcyclecounter();
+    int tk = 0;
+#define PHASE()                                            \
+    {                                                      \
+        __builtin_amdgcn_sched_barrier(0);                 \
+        unsigned long long now = __builtin_readcyclecounter(); \
+        tacc[tk] += now - tlast;                           \
+        tlast = now;                                       \
+        ++tk;                                              \
+        __builtin_amdgcn_sched_barrier(0);                 \
+    }
 #else
 #define PHASE() __builtin_amdgcn_sched_barrier(0)
 #endif
@@ -524,12 +535,23 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // counter is read one unit ahead, so its latency stays hidden.  n_chunks < 2^31 (checked on the host).
     constexpr unsigned UNIT = 4;
     const unsigned n_waves = gridDim.x * WAVES, cpr32 = (unsigned)cpr, n_chunks32 = (unsigned)n_chunks;
+    // The counter is bumped with a hand-issued atomic whose result stays in a vector register until the
+    // unit is started (one unit later): the compiler's own atomic sequence waits for the round trip at
+    // once.  The compiler does not count this load, hence the explicit wait before the value is used;
+    // by then the only other loads in flight are the next chunk's, which are needed at that point anyway.
     auto take = [&]() -> unsigned {
         unsigned v = 0;
-        if (lane == 0) v = atomicAdd(queue, 1u);
+        if (lane == 0) {
+            const unsigned one = 1u;
+            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v) : "v"(queue), "v"(one) : "memory");
+        }
+        return v;
+    };
+    auto uniform = [&](unsigned v) {
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
         return n_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     };
-    unsigned unit = blockIdx.x * WAVES + wave, next_unit = take(), in_unit = 0;
+    unsigned unit = blockIdx.x * WAVES + wave, next_raw = take(), in_unit = 0;
     unsigned chunk = unit * UNIT;
     ChunkIQ pre;
     float2 pre_tg = make_float2(0.f, 0.f);
@@ -541,13 +563,21 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
     }
     while (chunk < n_chunks32) {
+#ifdef ABL_TIMING
+        { unsigned long long now = __builtin_readcyclecounter(); tacc[18] += now - tlast; tlast = now; }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        { unsigned long long now = __builtin_readcyclecounter(); tacc[17] += now - tlast; tlast = now; }
+#endif
         commit_series<QAT>(ser, pre, lane, s0);
         tg_lds[lane] = pre_tg;
+#ifdef ABL_TIMING
+        { __builtin_amdgcn_sched_barrier(0); unsigned long long now = __builtin_readcyclecounter(); tacc[16] += now - tlast; tlast = now; __builtin_amdgcn_sched_barrier(0); }
+#endif
         const int64_t t0_cur = t0;
         if (++in_unit == UNIT) {
             in_unit = 0;
-            unit = next_unit;
-            next_unit = take();
+            unit = uniform(next_raw);
+            next_raw = take();
         }
         chunk = unit * UNIT + in_unit;
         pre_tg = make_float2(0.f, 0.f);
@@ -562,6 +592,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         for (int p = 0; p < 2; ++p) {
             // tiles beyond L inside a started pair run with zero upstream gradient: they add nothing
             if (t0_cur + 32 * p >= L) break;
+#ifdef ABL_TIMING
+            tk = 0;
+            PHASE();   // slot 0: everything outside the pair code (staging, prefetch, loop control)
+#endif
             const int cA = 2 * p, cB = 2 * p + 1;
             Tile A, B;
             float bA[8], bB[8];
@@ -604,6 +638,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         }
     }
 #undef PHASE
+#ifdef ABL_TIMING
+    if (lane == 0)
+        for (int k = 0; k < 20; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(queue + 16) + k, tacc[k]);
+#endif
 
     // ---- partial gradient row of this wave -> LDS, the workgroup's four rows are summed, one row per
     // workgroup goes to the slab (the staging regions are dead: every wave has left its loop)

@@ -1,0 +1,31 @@
+"""Read the per-phase cycle sums of an ABL_TIMING build of the fused Stage-1 kernel."""
+import sys, os, torch
+sys.path.insert(0, '.')
+import dpd_amd
+from dpd_amd import _lib as L
+from dpd_amd.data import ofdm_rows
+from dpd_amd.models import TDNNGeneratorQAT
+dev = torch.device('cuda:0'); torch.manual_seed(0)
+gen = TDNNGeneratorQAT().to(dev)
+B, S = 16384, 1029
+iq = ofdm_rows(B, S, seed=1234, device=dev); tgt = iq[:, 5:, :].contiguous()
+params = [gen.fc1.weight, gen.fc1.bias, gen.fc2.weight, gen.fc2.bias, gen.fc3.weight, gen.fc3.bias]
+wq = torch.empty(1554, device=dev); absmax = torch.zeros(8, device=dev)
+grads = torch.empty(1554, device=dev); loss = torch.zeros(1, device=dev)
+st = L.stream()
+L.call("dpd_gen_prepare_weights", *(L.fptr(p.detach()) for p in params), 0, L.fptr(wq), L.fptr(absmax), st)
+ws, wsp, wsn = L.workspace(dev)
+off = 1024 * 1560 * 4 + 64
+def go():
+    L.call("dpd_gen_mse_step", L.fptr(iq), B, S, L.fptr(tgt), L.fptr(wq), 0.2, 0, L.fptr(absmax), L.fptr(grads), L.fptr(loss), wsp, wsn, 2, st)
+go(); torch.cuda.synchronize()
+ws[off:off + 160].zero_()
+go(); torch.cuda.synchronize()
+t = ws[off:off + 160].view(torch.int64).cpu().tolist()
+t = t[:13] + [t[13 if False else 13]] + t[14:] if False else t
+pairs = B * 16 * 2   # tile pairs in the launch
+names = ["prefetch+div", "F1", "S1A", "S1B+V1A", "S2A+V1B", "S2B+V2A", "S3A+V2B", "S3B", "V3P", "S4AB+V4A", "S5A+V4B", "S5B+V5A", "S6A+V5B", "S6B", "-", "-", "commit", "vmwait", "looptail", "-"]
+tot = sum(t)
+for n, v in zip(names, t):
+    print("%-10s %8.1f cycles/pair  %5.1f%%" % (n, v / pairs, 100 * v / tot))
+print("total %.1f cycles/pair (100 MHz counter units if s_memtime is the constant-rate clock)" % (tot / pairs))
