@@ -52,9 +52,29 @@ constexpr int C_SLAB = 2952;  // 2945 gradients + padding
 
 DEV float scale_of(float amax, float qmax = 32767.0f) { return fmaxf(amax, 1e-8f) / qmax; }
 
-// quantise-dequantise with a given scale: clamp(rint(v / s), -2^15, 2^15 - 1) * s  (true division,
-// round-half-even: same arithmetic as the reference's StraightThroughQuantize)
-DEV float fq16(float v, float s) {
+// A 16-bit quantiser scale with its correctly rounded reciprocal (one double division per kernel).
+struct QS {
+    float s, inv;
+};
+DEV QS qs_of(float amax) {
+    QS q;
+    q.s = scale_of(amax);
+    q.inv = (float)(1.0 / (double)q.s);
+    return q;
+}
+DEV QS qs_one() { return QS{1.f, 1.f}; }
+
+// quantise-dequantise with a given scale: clamp(rint(v / s), -2^15, 2^15 - 1) * s, round-half-even: the
+// arithmetic of the reference's StraightThroughQuantize.  v / s is formed as q0 = v * inv,
+// q = fma(fma(-q0, s, v), inv, q0): with inv the correctly rounded reciprocal this is the correctly
+// rounded quotient (Markstein), i.e. bit-identical to the true division at a third of its cost.
+DEV float fq16(float v, QS k) {
+    const float q0 = v * k.inv;
+    float q = rintf(__builtin_fmaf(__builtin_fmaf(-q0, k.s, v), k.inv, q0));
+    q = fminf(fmaxf(q, -32768.0f), 32767.0f);
+    return q * k.s;
+}
+DEV float fq16(float v, float s) {   // one-off uses: true division
     float q = rintf(v / s);
     q = fminf(fmaxf(q, -32768.0f), 32767.0f);
     return q * s;

@@ -28,6 +28,9 @@ constexpr int WAVES = 4;
 #ifndef BWD_WAVES_PER_SIMD
 #define BWD_WAVES_PER_SIMD 2        // measured: 2 resident waves per SIMD (<= 256 registers, no spills) beat 3 with spills
 #endif
+#ifndef FWD_WAVES_PER_SIMD
+#define FWD_WAVES_PER_SIMD 4        // forward only: <= 128 registers
+#endif
 constexpr int CHUNK = 64;           // samples per wave iteration
 constexpr int SER_STRIDE = 71;      // words between series (71 = 7 mod 32: bank-disjoint operand reads)
 constexpr int SER_BASE0 = 5;
@@ -64,7 +67,6 @@ DEV int slot_word(int slot) {
     return SER_BASE0 + SER_STRIDE * type + 5 - tap;
 }
 DEV int swz(int s) { return 4 * ((s >> 1) & 3); }
-DEV int g_of_lane() { return (threadIdx.x & 63) >> 4; }
 
 struct Lane {
     int lane, j, g;
@@ -84,7 +86,7 @@ DEV void load_chunk_iq(ChunkIQ &c, const float2 *__restrict__ iqrow, int64_t t0,
 }
 // Derive the five series from the loaded points and park them in LDS.
 template <bool QAT>
-DEV void commit_series(float *ser, const ChunkIQ &c, int lane, float s0) {
+DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
 #pragma unroll
     for (int rep = 0; rep < 2; ++rep) {
         int tau = lane + 64 * rep;
@@ -108,13 +110,6 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, float s0) {
         p[4 * SER_STRIDE] = e4;
     }
 }
-template <bool QAT>
-DEV void stage_series(float *ser, const float2 *__restrict__ iqrow, int64_t t0, int64_t S, int lane, float s0) {
-    ChunkIQ c;
-    load_chunk_iq(c, iqrow, t0, S, lane);
-    commit_series<QAT>(ser, c, lane, s0);
-}
-
 struct FwdWeights {
     float A1[2][8];   // W1 tile t, step s: lane (i, g) holds W1[16t + i][slot 4s + g]
     float A2[2][4];   // W2[i][16t + 4g + r]
@@ -143,14 +138,6 @@ DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, in
     w.bias3 = f32x4{wq[G_B3], wq[G_B3 + 1], 0.f, 0.f};
 }
 
-struct TileFwd {
-    f32x4 m1[2];   // LeakyReLU multipliers (1 or slope) of the pre-activations
-    f32x4 h1[2];   // activations as fed to FC2 (quantised when QAT)
-    f32x4 m2;
-    f32x4 h2;
-    float y[2];    // tanh output, identical in the four lanes of a sample
-};
-
 // tanh to fp32 rounding level: odd series below 0.1 (next term 62/2835 x^9 < 2e-11), above it
 // (1 - t) / (1 + t) with t = exp(-2|x|) (no cancellation left: 1 - t >= 0.18)
 DEV float tanh_f32(float x) {
@@ -162,61 +149,12 @@ DEV float tanh_f32(float x) {
     return ax < 0.1f ? small : big;
 }
 
-DEV float swap16(float v) {   // value of lane ^ 16 (ds_swizzle bit mode: and 0x1f, or 0, xor 0x10)
-    return __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, v), 0x401F));
-}
-
-// Forward of one 16-sample tile.  DEPTH limits how far it runs (1: through act1, 2: through act2,
-// >= 3: to the output).  boff[s] = byte offset of this lane's FC1 operand for step s in tile 0.
+// Forward only.  DEPTH limits how far a tile runs (1: through act1, 2: through act2, >= 3: to the output);
+// the QAT instances with DEPTH 1..3 are the abs-max passes of the three activation quantisers.  Two tiles
+// (A, B) of the chunk run half a stage apart in one instruction stream (the VALU stage of one in the
+// shadow of the other's MFMAs); the output stage handles the pair at once, one (sample, output) per lane.
 template <bool QAT, int DEPTH>
-DEV void tile_forward(TileFwd &tf, const FwdWeights &w, const char *ser_bytes, const int (&boff)[8], int tile,
-                      float slope, float s1, float s2) {
-    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = {0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        float b = *reinterpret_cast<const float *>(ser_bytes + boff[s] + 64 * tile);
-        a0 = mfma4(w.A1[0][s], b, a0);
-        a1 = mfma4(w.A1[1][s], b, a1);
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        tf.m1[0][r] = a0[r] > 0.f ? 1.f : slope;
-        tf.m1[1][r] = a1[r] > 0.f ? 1.f : slope;
-    }
-    a0 *= tf.m1[0];
-    a1 *= tf.m1[1];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        tf.h1[0][r] = (QAT && DEPTH >= 2) ? fq16(a0[r], s1) : a0[r];
-        tf.h1[1][r] = (QAT && DEPTH >= 2) ? fq16(a1[r], s1) : a1[r];
-    }
-    if (DEPTH < 2) return;
-    f32x4 c0 = w.bias2, c1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        c0 = mfma4(w.A2[0][r], tf.h1[0][r], c0);
-        c1 = mfma4(w.A2[1][r], tf.h1[1][r], c1);
-    }
-    c0 += c1;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tf.m2[r] = c0[r] > 0.f ? 1.f : slope;
-    c0 *= tf.m2;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) tf.h2[r] = (QAT && DEPTH >= 3) ? fq16(c0[r], s2) : c0[r];
-    if (DEPTH < 3) return;
-    f32x4 z3 = w.bias3;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) z3 = mfma4(w.A3[r], tf.h2[r], z3);
-    // each lane evaluates one tanh (output g & 1) and fetches the other from lane ^ 16
-    const bool odd = (g_of_lane() & 1) != 0;
-    const float mine = tanh_f32(odd ? z3[1] : z3[0]);
-    const float other = swap16(mine);
-    tf.y[0] = odd ? other : mine;
-    tf.y[1] = odd ? mine : other;
-}
-
-template <bool QAT, int DEPTH>
-__global__ __launch_bounds__(WAVES * 64) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
+__global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
                                                              int64_t cpr, int64_t n_chunks,
                                                              const float *__restrict__ wq, float slope,
                                                              float *__restrict__ absmax, float2 *__restrict__ out) {
@@ -233,42 +171,134 @@ __global__ __launch_bounds__(WAVES * 64) void k_gen_fwd_mfma(const float2 *__res
         int slot = 4 * s + g;
         boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
-    float s0 = 1.f, s1 = 1.f, s2 = 1.f;
+    QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one();
     if (QAT) {
-        s0 = scale_of(absmax[0]);
-        if (DEPTH >= 2) s1 = scale_of(absmax[1]);
-        if (DEPTH >= 3) s2 = scale_of(absmax[2]);
+        s0 = qs_of(absmax[0]);
+        if (DEPTH >= 2) s1 = qs_of(absmax[1]);
+        if (DEPTH >= 3) s2 = qs_of(absmax[2]);
     }
     float amax = 0.f;
-    for (int64_t chunk = (int64_t)blockIdx.x * WAVES + wave; chunk < n_chunks; chunk += (int64_t)gridDim.x * WAVES) {
-        const int64_t row = chunk / cpr, t0 = (chunk - row * cpr) * CHUNK;
-        stage_series<QAT>(ser, iq + row * S, t0, S, lane, s0);
-        float2 ysel = make_float2(0.f, 0.f);
+    const char *const ser_b = reinterpret_cast<const char *>(ser);
+    const bool odd = (g & 1) != 0;
+
+    struct Tile {
+        f32x4 a0, a1, ha, hb, c0, c1, h2, z3;
+    };
+    auto S1 = [&](Tile &t, int c) {
+        t.a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
+        t.a1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            // with zero-size tiles skipped the wave stays convergent: the bound is wave-uniform
-            if (t0 + 16 * c >= L) break;
-            TileFwd tf;
-            tile_forward<QAT, DEPTH>(tf, w, reinterpret_cast<const char *>(ser), boff, c, slope, s1, s2);
-            const bool valid = (t0 + 16 * c + j) < L;
-            if (QAT && DEPTH == 1) {
+        for (int s = 0; s < 8; ++s) {
+            float b = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
+            t.a0 = mfma4(w.A1[0][s], b, t.a0);
+            t.a1 = mfma4(w.A1[1][s], b, t.a1);
+        }
+    };
+    auto V1 = [&](Tile &t, bool valid) {
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+        for (int r = 0; r < 4; ++r) {
+            const float x0 = lrelu(t.a0[r], slope), x1 = lrelu(t.a1[r], slope);
+            t.ha[r] = (QAT && DEPTH >= 2) ? fq16(x0, s1) : x0;
+            t.hb[r] = (QAT && DEPTH >= 2) ? fq16(x1, s1) : x1;
+            if (QAT && DEPTH == 1) amax = fmaxf(amax, valid ? fmaxf(fabsf(x0), fabsf(x1)) : 0.f);
+        }
+    };
+    auto S2 = [&](Tile &t) {
+        t.c0 = w.bias2;
+        t.c1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) amax = fmaxf(amax, valid ? fabsf(tf.h1[t][r]) : 0.f);
-            } else if (QAT && DEPTH == 2) {
+        for (int r = 0; r < 4; ++r) {
+            t.c0 = mfma4(w.A2[0][r], t.ha[r], t.c0);
+            t.c1 = mfma4(w.A2[1][r], t.hb[r], t.c1);
+        }
+    };
+    auto V2 = [&](Tile &t, bool valid) {
+        t.c0 += t.c1;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) amax = fmaxf(amax, valid ? fabsf(tf.h2[r]) : 0.f);
+        for (int r = 0; r < 4; ++r) {
+            const float x = lrelu(t.c0[r], slope);
+            t.h2[r] = (QAT && DEPTH >= 3) ? fq16(x, s2) : x;
+            if (QAT && DEPTH == 2) amax = fmaxf(amax, valid ? fabsf(x) : 0.f);
+        }
+    };
+    auto S3 = [&](Tile &t) {
+        t.z3 = w.bias3;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t.z3 = mfma4(w.A3[r], t.h2[r], t.z3);
+    };
+#define PHASE() __builtin_amdgcn_sched_barrier(0)
+
+    // the chunk's 69 IQ points are loaded one chunk ahead; (row, position) advance by a fixed step
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    int64_t chunk = (int64_t)blockIdx.x * WAVES + wave;
+    const int64_t step_rows = stride / cpr, step_pos = stride - step_rows * cpr;
+    int64_t row = chunk / cpr, pos = chunk - row * cpr;
+    ChunkIQ pre;
+    int64_t t0 = 0;
+    if (chunk < n_chunks) {
+        t0 = pos * CHUNK;
+        load_chunk_iq(pre, iq + row * S, t0, S, lane);
+    }
+    while (chunk < n_chunks) {
+        commit_series<QAT>(ser, pre, lane, s0);
+        const int64_t t0_cur = t0, row_cur = row;
+        chunk += stride;
+        row += step_rows;
+        pos += step_pos;
+        if (pos >= cpr) {
+            pos -= cpr;
+            ++row;
+        }
+        if (chunk < n_chunks) {
+            t0 = pos * CHUNK;
+            load_chunk_iq(pre, iq + row * S, t0, S, lane);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            if (t0_cur + 32 * p >= L) break;      // wave-uniform: the wave stays convergent
+            const int cA = 2 * p, cB = 2 * p + 1;
+            const bool vA = (t0_cur + 16 * cA + j) < L, vB = (t0_cur + 16 * cB + j) < L;
+            Tile A, B;
+            S1(A, cA);
+            PHASE();
+            S1(B, cB);
+            V1(A, vA);
+            PHASE();
+            if (DEPTH >= 2) {
+                S2(A);
+                V1(B, vB);
+                PHASE();
+                S2(B);
+                V2(A, vA);
+                PHASE();
+                if (DEPTH >= 3) {
+                    S3(A);
+                    V2(B, vB);
+                    PHASE();
+                    S3(B);
+                    PHASE();
+                    // lane (g, j): output g & 1 of sample j of tile g >> 1 (every lane group holds z3 of its sample j)
+                    const float zA = odd ? A.z3[1] : A.z3[0], zB = odd ? B.z3[1] : B.z3[0];
+                    const float y = tanh_f32(g >= 2 ? zB : zA);
+                    const int64_t t = t0_cur + 32 * p + 16 * (g >> 1) + j;
+                    if (QAT) amax = fmaxf(amax, t < L ? fabsf(y) : 0.f);
+                    // one row swap pairs the two outputs of a sample: rows 0 and 2 then store float2
+                    const unsigned bits = __builtin_bit_cast(unsigned, y);
+                    const auto r = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);
+                    unsigned u0 = r[0], u1 = r[1];
+                    asm volatile("" : "+v"(u0), "+v"(u1));   // see the note on folded swap results in the backward kernel
+                    if (!odd && t < L)
+                        out[row_cur * L + t] = make_float2(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1));
+                } else {
+                    V2(B, vB);
+                }
             } else {
-                if (QAT) amax = fmaxf(amax, valid ? fmaxf(fabsf(tf.y[0]), fabsf(tf.y[1])) : 0.f);
-                if (g == c) ysel = make_float2(tf.y[0], tf.y[1]);
+                V1(B, vB);
             }
         }
-        if (DEPTH >= 3) {
-            int64_t t = t0 + lane;  // lane (g, j) holds sample 16g + j of the chunk
-            if (t < L) out[row * L + t] = ysel;
-        }
     }
+#undef PHASE
     if (QAT) {
         amax = wave_max(amax);
         if (lane == 0) atomic_max_nonneg(absmax + DEPTH, amax);
@@ -334,12 +364,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     }
     char *const ser_b = reinterpret_cast<char *>(ser);
 
-    float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+    QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
     if (QAT) {
-        s0 = scale_of(absmax[0]);
-        s1 = scale_of(absmax[1]);
-        s2 = scale_of(absmax[2]);
-        s3 = scale_of(absmax[3]);
+        s0 = qs_of(absmax[0]);
+        s1 = qs_of(absmax[1]);
+        s2 = qs_of(absmax[2]);
+        s3 = qs_of(absmax[3]);
     }
     f32x4 dW1[2][2], dW2[2];
 #pragma unroll
@@ -709,7 +739,7 @@ int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st)
         return DPD_OK;
     }
     const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
-    const dim3 grid(mfma_grid(n_chunks)), block(WAVES * 64);
+    const dim3 grid(mfma_grid(n_chunks, FWD_WAVES_PER_SIMD)), block(WAVES * 64);
     float2 *o = reinterpret_cast<float2 *>(out);
 #define GO(Q, D) hipLaunchKernelGGL((k_gen_fwd_mfma<Q, D>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
                                     p.slope, p.absmax, o)

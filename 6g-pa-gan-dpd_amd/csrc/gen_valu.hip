@@ -68,11 +68,11 @@ __global__ __launch_bounds__(FWD_TPB) void k_gen_fwd(const float *__restrict__ x
     __shared__ float sw[G_NP + 2];
     for (int i = threadIdx.x; i < G_NP; i += FWD_TPB) sw[i] = wq[i];
     __syncthreads();
-    float s0 = 1.f, s1 = 1.f, s2 = 1.f;
+    QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one();
     if (QAT) {
-        if (DEPTH >= 1) s0 = scale_of(absmax[0]);
-        if (DEPTH >= 2) s1 = scale_of(absmax[1]);
-        if (DEPTH >= 3) s2 = scale_of(absmax[2]);
+        if (DEPTH >= 1) s0 = qs_of(absmax[0]);
+        if (DEPTH >= 2) s1 = qs_of(absmax[1]);
+        if (DEPTH >= 3) s2 = qs_of(absmax[2]);
     }
     float amax = 0.f;
     for (int64_t n = (int64_t)blockIdx.x * FWD_TPB + threadIdx.x; n < N; n += (int64_t)gridDim.x * FWD_TPB) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(FWD_TPB) void k_gen_fwd(const float *__restrict__ x
 
 __global__ __launch_bounds__(256) void k_quantize_output(float *__restrict__ out, int64_t n,
                                                          const float *__restrict__ absmax) {
-    float s = scale_of(absmax[3]);
+    const QS s = qs_of(absmax[3]);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256)
         out[i] = fq16(out[i], s);
 }
@@ -144,12 +144,12 @@ __global__ __launch_bounds__(BWD_TPB) void k_gen_bwd(const float *__restrict__ x
     const int tid = threadIdx.x;
     for (int i = tid; i < G_NP; i += BWD_TPB) sw[i] = wq[i];
     __syncthreads();
-    float s0 = 1.f, s1 = 1.f, s2 = 1.f, s3 = 1.f;
+    QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
     if (QAT) {
-        s0 = scale_of(absmax[0]);
-        s1 = scale_of(absmax[1]);
-        s2 = scale_of(absmax[2]);
-        s3 = scale_of(absmax[3]);
+        s0 = qs_of(absmax[0]);
+        s1 = qs_of(absmax[1]);
+        s2 = qs_of(absmax[2]);
+        s3 = qs_of(absmax[3]);
     }
     // entry ownership
     int gcol[BWD_EPT], acol[BWD_EPT];
@@ -330,7 +330,7 @@ __global__ __launch_bounds__(64) void k_prepare_weights(const float *__restrict_
     }
     float am = 0.f;
     for (int k = 0; k < len; ++k) am = fmaxf(am, fabsf(src[k]));
-    float s = scale_of(am);
+    const QS s = qs_of(am);
     for (int k = 0; k < len; ++k) dst[k] = qat ? fq16(src[k], s) : src[k];
     float a0 = wave_max(which == 0 ? am : 0.f);
     float a1 = wave_max(which == 1 ? am : 0.f);
