@@ -304,11 +304,18 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__r
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const int64_t ntiles = (N + 15) >> 4;
     float acc = 0.f;
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+    // the tile's input is loaded one tile ahead (one value per lane): no HBM latency in front of the MFMAs
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    auto fetch = [&](int64_t tile) {
+        const int64_t n = tile * 16 + j;
+        return (tile < ntiles && n < N) ? (g < 2 ? x[2 * n + g] : cond[2 * n + g - 2]) : 0.f;
+    };
+    float in_next = fetch((int64_t)blockIdx.x * WAVES + wave);
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
         const int64_t n = tile * 16 + j;
         const bool valid = n < N;
-        float in = 0.f;
-        if (valid) in = g < 2 ? x[2 * n + g] : cond[2 * n + g - 2];
+        const float in = in_next;
+        in_next = fetch(tile + stride);
         Acts a;
         tile_forward(a, lds, lane, in, slope);
         if (valid && g == 0) {
@@ -360,14 +367,23 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_bwd_mfma(const float *__r
     const f32x4 w4 = quad(lds, Q_W4, lane);
     float ssum = 0.f;
     const int64_t ntiles = (N + 15) >> 4;
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+    // the tile's input (and upstream gradient) is loaded one tile ahead
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    auto fetch_in = [&](int64_t tile) {
+        const int64_t n = tile * 16 + j;
+        return (tile < ntiles && n < N) ? (g < 2 ? x[2 * n + g] : cond[2 * n + g - 2]) : 0.f;
+    };
+    auto fetch_gs = [&](int64_t tile) {
+        const int64_t n = tile * 16 + j;
+        return (tile < ntiles && n < N) ? (gscore ? gscore[n] : gconst) : 0.f;
+    };
+    float in_next = fetch_in((int64_t)blockIdx.x * WAVES + wave), gs_next = fetch_gs((int64_t)blockIdx.x * WAVES + wave);
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
         const int64_t n = tile * 16 + j;
         const bool valid = n < N;
-        float in = 0.f, gs = 0.f;
-        if (valid) {
-            in = g < 2 ? x[2 * n + g] : cond[2 * n + g - 2];
-            gs = gscore ? gscore[n] : gconst;
-        }
+        const float in = in_next, gs = gs_next;
+        in_next = fetch_in(tile + stride);
+        gs_next = fetch_gs(tile + stride);
         Acts a;
         tile_forward(a, lds, lane, in, slope);
         ssum += (valid && g == 0) ? a.score : 0.f;
@@ -440,11 +456,12 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_a_mfma(const float *__restric
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const f32x4 w4 = quad(lds, Q_W4, lane);
     const int64_t ntiles = (N + 15) >> 4;
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+    // the tile's input is loaded one tile ahead
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    auto fetch = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
-        const bool valid = n < N;
         float in = 0.f;
-        if (valid) {
+        if (tile < ntiles && n < N) {
             if (g < 2) {
                 const float al = alpha[ROW1 ? n : n / L];
                 in = al * real[2 * n + g] + (1.f - al) * fake[2 * n + g];
@@ -452,6 +469,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_a_mfma(const float *__restric
                 in = cond[2 * n + g - 2];
             }
         }
+        return in;
+    };
+    float in_next = fetch((int64_t)blockIdx.x * WAVES + wave);
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
+        const int64_t n = tile * 16 + j;
+        const bool valid = n < N;
+        const float in = in_next;
+        in_next = fetch(tile + stride);
         Acts a;
         tile_forward(a, lds, lane, in, slope);
         f32x4 m1[4], m2[2];
@@ -538,17 +563,28 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
     const f32x4 w4 = quad(lds, Q_W4, lane);
     const f32x4 a1 = quad(lds, Q_A1, lane);
     const int64_t ntiles = (N + 15) >> 4;
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += (int64_t)gridDim.x * WAVES) {
+    // the tile's mask word, input gradient and row coefficient are loaded one tile ahead
+    const int64_t stride = (int64_t)gridDim.x * WAVES;
+    unsigned bits_next = 0u;
+    float2 gh_next = make_float2(0.f, 0.f);
+    auto fetch = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
-        const bool valid = n < N;
-        const unsigned bits = maskw[tile * 64 + lane];
-        float gh0 = 0.f, gh1 = 0.f;
-        if (valid) {
-            const float2 gv = gin[n];
-            const float c = rowc[ROW1 ? n : n / L];
-            gh0 = c * gv.x;
-            gh1 = c * gv.y;
+        bits_next = 0u;
+        gh_next = make_float2(0.f, 0.f);
+        if (tile < ntiles) {
+            bits_next = maskw[tile * 64 + lane];
+            if (n < N) {
+                const float2 gv = gin[n];
+                const float c = rowc[ROW1 ? n : n / L];
+                gh_next = make_float2(c * gv.x, c * gv.y);
+            }
         }
+    };
+    fetch((int64_t)blockIdx.x * WAVES + wave);
+    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
+        const unsigned bits = bits_next;
+        const float gh0 = gh_next.x, gh1 = gh_next.y;
+        fetch(tile + stride);
         f32x4 m1[4], m2[2], m3;
 #pragma unroll
         for (int t = 0; t < 4; ++t)

@@ -62,7 +62,8 @@ extern "C" int dpd_gen_absmax_pass(int stage, const float *x, int64_t B, int64_t
     GenProblem p;
     int rc = make_problem(p, x, B, S, pre_assembled, wq, slope, 1, absmax);
     if (rc) return rc;
-    DPD_REQUIRE(stage < 3 || out, DPD_ERR_INVALID_ARG, "absmax_pass: stage 3 writes the output, out is null");
+    DPD_REQUIRE(stage < 3 || out || use_mfma(p, impl), DPD_ERR_INVALID_ARG,
+                "absmax_pass: stage 3 writes the output (optional only for IQ input of >= 4096 samples), out is null");
     hipStream_t st = as_stream(stream);
     DPD_HIP(hipMemsetAsync(absmax + stage, 0, sizeof(float), st));
     return forward_dispatch(p, stage, out, impl, st);
@@ -134,17 +135,30 @@ extern "C" int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const flo
     return backward_common(p, nullptr, target, grads, loss, nullptr, ws, ws_bytes, impl, as_stream(stream));
 }
 
-// Generator forward with scales already known (QAT: absmax[0..3] filled by the abs-max passes):
-// one pass to the output plus the output quantiser.  Used by the generator -> PA chain.
-int gen_forward_for_chain(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
-                          const float *absmax, float *out, hipStream_t st) {
+// Chain iq -> generator -> PA twin with the generator's scales already known (QAT: absmax[0..3] filled
+// by the abs-max passes).  Large batches: one kernel (the generator output never makes the round trip
+// through HBM; it is written only if the caller asks for it).  Otherwise: forward to the output, the
+// output quantiser, then the PA kernel.
+extern "C" int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
+                                  const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
+                                  float *dpd_out, float *y, void *stream) {
+    DPD_REQUIRE(y && coef_re && coef_im, DPD_ERR_INVALID_ARG, "gen_pa_forward: null pointer");
+    DPD_REQUIRE(K >= 1 && K <= 8 && M >= 1 && M <= 16, DPD_ERR_INVALID_ARG, "gen_pa_forward: K in 1..8, M in 1..16");
     GenProblem p;
     int rc = make_problem(p, iq, B, S, 0, wq, slope, qat, const_cast<float *>(absmax));
     if (rc) return rc;
+    DPD_REQUIRE(p.L >= M, DPD_ERR_SHAPE, "Sequence length %lld must be >= memory depth %d", (long long)p.L, M);
     if (p.N == 0) return DPD_OK;
-    if (!p.qat) return forward_dispatch(p, 4, out, DPD_IMPL_AUTO, st);
-    // the pass-3 kernel rewrites absmax[3] with the same value it already holds (max is idempotent)
-    rc = forward_dispatch(p, 3, out, DPD_IMPL_AUTO, st);
+    hipStream_t st = as_stream(stream);
+    if (use_mfma(p, DPD_IMPL_AUTO)) return gen_mfma_pa_forward(p, coef_re, coef_im, K, M, dpd_out, y, st);
+    DPD_REQUIRE(dpd_out, DPD_ERR_INVALID_ARG, "gen_pa_forward: small batches need dpd_out as the intermediate buffer");
+    if (!p.qat) {
+        rc = forward_dispatch(p, 4, dpd_out, DPD_IMPL_AUTO, st);
+    } else {
+        // the pass-3 kernel rewrites absmax[3] with the same value it already holds (max is idempotent)
+        rc = forward_dispatch(p, 3, dpd_out, DPD_IMPL_AUTO, st);
+        if (!rc) rc = gen_launch_quantize_output(dpd_out, p.N * 2, absmax, st);
+    }
     if (rc) return rc;
-    return gen_launch_quantize_output(out, p.N * 2, absmax, st);
+    return dpd_pa_forward(dpd_out, B, p.L, coef_re, coef_im, K, M, y, stream);
 }

@@ -21,6 +21,9 @@ int gen_valu_backward(const GenProblem &p, const float *grad_out, const float *t
                       float *slab, int *n_partials, hipStream_t st);
 
 int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st);
+// one kernel: generator forward (final scales in p.absmax when p.qat) + memory-polynomial PA; out may be NULL
+int gen_mfma_pa_forward(const GenProblem &p, const float *cre, const float *cim, int K, int M, float *out, float *y,
+                        hipStream_t st);
 int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *target,
                       float *slab, int *n_partials, hipStream_t st);
 

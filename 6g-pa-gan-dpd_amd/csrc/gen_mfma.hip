@@ -153,16 +153,39 @@ DEV float tanh_f32(float x) {
 // the QAT instances with DEPTH 1..3 are the abs-max passes of the three activation quantisers.  Two tiles
 // (A, B) of the chunk run half a stage apart in one instruction stream (the VALU stage of one in the
 // shadow of the other's MFMAs); the output stage handles the pair at once, one (sample, output) per lane.
-template <bool QAT, int DEPTH>
+//
+// PA: the chain generator -> PA twin in the same kernel (DEPTH 4; with QAT the output quantiser runs
+// in the kernel, absmax[3] must hold its final value).  A chunk then owns 64 - (M - 1) PA outputs: its
+// 64 generator outputs are parked in LDS and every lane evaluates one output of the memory polynomial
+// (the arithmetic of k_pa_fwd); chunks of a row overlap by M - 1 generator outputs.
+struct PaArgs {
+    const float *cre, *cim;   // [K, M]
+    int K, M;
+    float2 *y;                // [B, L - M + 1]
+    int64_t OL;
+};
+template <bool QAT, int DEPTH, bool PA>
 __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
                                                              int64_t cpr, int64_t n_chunks,
                                                              const float *__restrict__ wq, float slope,
-                                                             float *__restrict__ absmax, float2 *__restrict__ out) {
+                                                             float *__restrict__ absmax, float2 *__restrict__ out,
+                                                             PaArgs pa) {
+    static_assert(!PA || DEPTH == 4, "the fused chain is a final forward");
     __shared__ float lds[WAVES][SER_WORDS];
+    __shared__ float pa_re[PA ? 128 : 1], pa_im[PA ? 128 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     float *ser = lds[wave];
     ser[ZERO_W + lane] = 0.f;
     ser[ONE_W + lane] = 1.f;
+    if (PA) {
+        for (int i = threadIdx.x; i < pa.K * pa.M; i += WAVES * 64) {
+            pa_re[i] = pa.cre[i];
+            pa_im[i] = pa.cim[i];
+        }
+        __syncthreads();
+    }
+    const int chunk_step = PA ? CHUNK - (pa.M - 1) : CHUNK;   // outputs a chunk advances by
+    float2 *const ybuf = reinterpret_cast<float2 *>(ser + TG_W);   // PA: the chunk's generator outputs
     FwdWeights w;
     load_fwd_weights(w, wq, j, g);
     int boff[8];
@@ -171,11 +194,12 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         int slot = 4 * s + g;
         boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
-    QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one();
+    QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
     if (QAT) {
         s0 = qs_of(absmax[0]);
         if (DEPTH >= 2) s1 = qs_of(absmax[1]);
         if (DEPTH >= 3) s2 = qs_of(absmax[2]);
+        if (PA) s3 = qs_of(absmax[3]);
     }
     float amax = 0.f;
     const char *const ser_b = reinterpret_cast<const char *>(ser);
@@ -236,7 +260,7 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
     ChunkIQ pre;
     int64_t t0 = 0;
     if (chunk < n_chunks) {
-        t0 = pos * CHUNK;
+        t0 = pos * chunk_step;
         load_chunk_iq(pre, iq + row * S, t0, S, lane);
     }
     while (chunk < n_chunks) {
@@ -250,7 +274,7 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
             ++row;
         }
         if (chunk < n_chunks) {
-            t0 = pos * CHUNK;
+            t0 = pos * chunk_step;
             load_chunk_iq(pre, iq + row * S, t0, S, lane);
         }
         __builtin_amdgcn_wave_barrier();
@@ -280,16 +304,24 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                     PHASE();
                     // lane (g, j): output g & 1 of sample j of tile g >> 1 (every lane group holds z3 of its sample j)
                     const float zA = odd ? A.z3[1] : A.z3[0], zB = odd ? B.z3[1] : B.z3[0];
-                    const float y = tanh_f32(g >= 2 ? zB : zA);
+                    float y = tanh_f32(g >= 2 ? zB : zA);
                     const int64_t t = t0_cur + 32 * p + 16 * (g >> 1) + j;
-                    if (QAT) amax = fmaxf(amax, t < L ? fabsf(y) : 0.f);
+                    if (QAT && !PA) amax = fmaxf(amax, t < L ? fabsf(y) : 0.f);
+                    if (QAT && PA) y = fq16(y, s3);
                     // one row swap pairs the two outputs of a sample: rows 0 and 2 then store float2
                     const unsigned bits = __builtin_bit_cast(unsigned, y);
                     const auto r = __builtin_amdgcn_permlane16_swap(bits, bits, false, false);
                     unsigned u0 = r[0], u1 = r[1];
                     asm volatile("" : "+v"(u0), "+v"(u1));   // see the note on folded swap results in the backward kernel
-                    if (!odd && t < L)
-                        out[row_cur * L + t] = make_float2(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1));
+                    const float2 yy = make_float2(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1));
+                    if (PA) {
+                        if (!odd) ybuf[32 * p + 16 * (g >> 1) + j] = yy;
+                        // generator outputs in the overlap belong to the next chunk of the row
+                        const bool mine = t < t0_cur + chunk_step || t0_cur + chunk_step >= pa.OL;
+                        if (out && !odd && t < L && mine) out[row_cur * L + t] = yy;
+                    } else {
+                        if (out && !odd && t < L) out[row_cur * L + t] = yy;
+                    }
                 } else {
                     V2(B, vB);
                 }
@@ -297,9 +329,29 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                 V1(B, vB);
             }
         }
+        if (PA) {
+            __builtin_amdgcn_wave_barrier();
+            const int64_t n = t0_cur + lane;                     // PA output of this lane
+            if (lane < chunk_step && n < pa.OL) {
+                float yr = 0.f, yi = 0.f;
+                for (int m = 0; m < pa.M; ++m) {
+                    const float2 v = ybuf[lane + pa.M - 1 - m];
+                    const float pw = v.x * v.x + v.y * v.y;
+                    float pr = pa_re[(pa.K - 1) * pa.M + m], pi = pa_im[(pa.K - 1) * pa.M + m];
+                    for (int k = pa.K - 2; k >= 0; --k) {
+                        pr = __builtin_fmaf(pr, pw, pa_re[k * pa.M + m]);
+                        pi = __builtin_fmaf(pi, pw, pa_im[k * pa.M + m]);
+                    }
+                    yr += v.x * pr - v.y * pi;
+                    yi += v.x * pi + v.y * pr;
+                }
+                pa.y[row_cur * pa.OL + n] = make_float2(yr, yi);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
     }
 #undef PHASE
-    if (QAT) {
+    if (QAT && !PA) {
         amax = wave_max(amax);
         if (lane == 0) atomic_max_nonneg(absmax + DEPTH, amax);
     }
@@ -454,11 +506,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     const int tg_off = 2 * (16 * (g >> 1) + j) + (g & 1);
     auto V3P = [&](Tile &A, Tile &B, int p, int64_t t0_cur) {
         const float zA = odd ? A.z3[1] : A.z3[0], zB = odd ? B.z3[1] : B.z3[0];
-#ifdef ABL_NO_TANH
-        const float y = g >= 2 ? zB : zA;
-#else
         const float y = tanh_f32(g >= 2 ? zB : zA);
-#endif
         const bool valid = (t0_cur + 32 * p + 16 * (g >> 1) + j) < L;
         const float v = tg_f[tg_off + 64 * p];
         float gup;
@@ -517,9 +565,6 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         *reinterpret_cast<f32x4 *>(gz_b + wr32 + 64) = t.e1;
     };
     auto S6 = [&](int c, int buf) {   // samples move from lanes to the MFMA K axis through the LDS tiles
-#ifdef ABL_NO_S6
-        return;
-#endif
         const char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
         const char *h1_b = ser_b + 4 * (H1_W + TILE_W * buf);
 #pragma unroll
@@ -654,6 +699,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             S4(B);
             V4(A, 0);
             PHASE();
+
             S5(A);
             V4(B, 1);
             PHASE();
@@ -741,13 +787,33 @@ int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st)
     const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
     const dim3 grid(mfma_grid(n_chunks, FWD_WAVES_PER_SIMD)), block(WAVES * 64);
     float2 *o = reinterpret_cast<float2 *>(out);
-#define GO(Q, D) hipLaunchKernelGGL((k_gen_fwd_mfma<Q, D>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
-                                    p.slope, p.absmax, o)
+    const PaArgs none{nullptr, nullptr, 0, 0, nullptr, 0};
+#define GO(Q, D) hipLaunchKernelGGL((k_gen_fwd_mfma<Q, D, false>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
+                                    p.slope, p.absmax, o, none)
     if (!p.qat) GO(false, 4);
     else if (depth == 1) GO(true, 1);
     else if (depth == 2) GO(true, 2);
     else GO(true, 3);
 #undef GO
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+// Fused chain generator -> PA twin; out (generator output) may be NULL.  K * M <= 128, M <= 16.
+int gen_mfma_pa_forward(const GenProblem &p, const float *cre, const float *cim, int K, int M, float *out, float *y,
+                        hipStream_t st) {
+    const float2 *iq = reinterpret_cast<const float2 *>(p.x);
+    const int64_t OL = p.L - M + 1, step = CHUNK - (M - 1);
+    const int64_t cpr = (OL + step - 1) / step, n_chunks = cpr * p.B;
+    const dim3 grid(mfma_grid(n_chunks, FWD_WAVES_PER_SIMD)), block(WAVES * 64);
+    const PaArgs pa{cre, cim, K, M, reinterpret_cast<float2 *>(y), OL};
+    float2 *o = reinterpret_cast<float2 *>(out);
+    if (p.qat)
+        hipLaunchKernelGGL((k_gen_fwd_mfma<true, 4, true>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, p.slope,
+                           p.absmax, o, pa);
+    else
+        hipLaunchKernelGGL((k_gen_fwd_mfma<false, 4, true>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, p.slope,
+                           p.absmax, o, pa);
     DPD_LAUNCH_CHECK();
     return DPD_OK;
 }

@@ -22,17 +22,30 @@ DEV void load_coefs(float *sre, float *sim, const float *__restrict__ cre, const
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void k_pa_fwd(const float2 *__restrict__ x, int64_t S, int64_t OL, int64_t N,
+// QUANT: x is the generator's unquantised output and absmax3 its abs-max: the 16-bit output quantiser is
+// applied on load and the quantised samples are written back in place.  Quantising is idempotent for a
+// fixed scale, so it does not matter whether a neighbour lane has already rewritten a sample.
+template <bool QUANT>
+__global__ __launch_bounds__(256) void k_pa_fwd(float2 *__restrict__ x, int64_t S, int64_t OL, int64_t N,
                                                 const float *__restrict__ cre, const float *__restrict__ cim, int K,
-                                                int M, float2 *__restrict__ y) {
+                                                int M, const float *__restrict__ absmax3, float2 *__restrict__ y) {
     __shared__ float sre[MAXK * MAXM], sim[MAXK * MAXM];
     load_coefs(sre, sim, cre, cim, K, M);
+    QS qs = qs_one();
+    if (QUANT) qs = qs_of(absmax3[0]);
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < N; i += (int64_t)gridDim.x * 256) {
         const int64_t b = i / OL, n = i - b * OL;
-        const float2 *row = x + b * S + n;
+        float2 *row = x + b * S + n;
         float yr = 0.f, yi = 0.f;
         for (int m = 0; m < M; ++m) {
-            const float2 v = row[M - 1 - m];
+            float2 v = row[M - 1 - m];
+            if (QUANT) {
+                v.x = fq16(v.x, qs);
+                v.y = fq16(v.y, qs);
+                // sample n + M - 1 - m is rewritten by the output that reads it through tap M - 1 (the
+                // row's first output also rewrites the M - 1 samples before it)
+                if (m == 0 || n == 0) row[M - 1 - m] = v;
+            }
             const float p = v.x * v.x + v.y * v.y;
             float pr = sre[(K - 1) * M + m], pi = sim[(K - 1) * M + m];
             for (int k = K - 2; k >= 0; --k) {
@@ -96,8 +109,22 @@ extern "C" int dpd_pa_forward(const float *x, int64_t B, int64_t S, const float 
     DPD_REQUIRE(y, DPD_ERR_INVALID_ARG, "pa_forward: y is null");
     const int64_t OL = S - M + 1, N = B * OL;
     if (N == 0) return DPD_OK;
-    hipLaunchKernelGGL(k_pa_fwd, dim3(grid_for(N, 256)), dim3(256), 0, as_stream(stream),
-                       reinterpret_cast<const float2 *>(x), S, OL, N, coef_re, coef_im, K, M,
+    hipLaunchKernelGGL(k_pa_fwd<false>, dim3(grid_for(N, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<float2 *>(const_cast<float *>(x)), S, OL, N, coef_re, coef_im, K, M, nullptr,
+                       reinterpret_cast<float2 *>(y));
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+extern "C" int dpd_quant_pa_forward(float *x, int64_t B, int64_t S, const float *absmax3, const float *coef_re,
+                                    const float *coef_im, int K, int M, float *y, void *stream) {
+    int rc = pa_check(x, B, S, coef_re, coef_im, K, M);
+    if (rc) return rc;
+    DPD_REQUIRE(y && absmax3, DPD_ERR_INVALID_ARG, "quant_pa_forward: null pointer");
+    const int64_t OL = S - M + 1, N = B * OL;
+    if (N == 0) return DPD_OK;
+    hipLaunchKernelGGL(k_pa_fwd<true>, dim3(grid_for(N, 256)), dim3(256), 0, as_stream(stream),
+                       reinterpret_cast<float2 *>(x), S, OL, N, coef_re, coef_im, K, M, absmax3,
                        reinterpret_cast<float2 *>(y));
     DPD_LAUNCH_CHECK();
     return DPD_OK;
@@ -115,16 +142,4 @@ extern "C" int dpd_pa_backward(const float *x, int64_t B, int64_t S, const float
                        reinterpret_cast<const float2 *>(gy), reinterpret_cast<float2 *>(gx));
     DPD_LAUNCH_CHECK();
     return DPD_OK;
-}
-
-int gen_forward_for_chain(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
-                          const float *absmax, float *out, hipStream_t st);
-
-extern "C" int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
-                                  const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
-                                  float *dpd_out, float *y, void *stream) {
-    DPD_REQUIRE(dpd_out && y, DPD_ERR_INVALID_ARG, "gen_pa_forward: dpd_out and y are required");
-    int rc = gen_forward_for_chain(iq, B, S, wq, slope, qat, absmax, dpd_out, as_stream(stream));
-    if (rc) return rc;
-    return dpd_pa_forward(dpd_out, B, S - DPD_GEN_MEMORY, coef_re, coef_im, K, M, y, stream);
 }

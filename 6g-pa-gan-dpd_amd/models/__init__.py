@@ -7,3 +7,4 @@ from .pa_digital_twin import PADigitalTwin, VolterraPA, create_pa_digital_twin  
 from .discriminator import (  # noqa: F401
     Discriminator, SpectralNormLinear, WassersteinLoss, compute_gradient_penalty, create_discriminator,
 )
+from .chain import dpd_pa_chain  # noqa: F401  (no counterpart in the reference: the fused validation chain)

@@ -74,7 +74,8 @@ int dpd_gen_prepare_weights(const float *w1, const float *b1, const float *w2, c
  * 2: act2 -> absmax[2]; 3: tanh output -> absmax[3] and the unquantised output into `out`.
  * x is iq [B,S,2] (pre_assembled == 0) or features [B,30] (pre_assembled != 0, S ignored).
  * absmax[stage] is overwritten; earlier entries are read.  Between passes a data-parallel caller
- * may max-reduce absmax[stage] across ranks. */
+ * may max-reduce absmax[stage] across ranks.  `out` is used by stage 3 only; there it may be NULL
+ * for IQ input of >= 4096 samples (a caller that continues with dpd_gen_pa_forward needs no copy). */
 int dpd_gen_absmax_pass(int stage, const float *x, int64_t B, int64_t S, int pre_assembled,
                         const float *wq, float slope, float *absmax, float *out, int impl, void *stream);
 
@@ -111,14 +112,22 @@ int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const float *target,
 int dpd_pa_forward(const float *x, int64_t B, int64_t S, const float *coef_re, const float *coef_im,
                    int K, int M, float *y, void *stream);
 
+/* The generator's output quantiser (TDNNGeneratorQAT.forward, models/tdnn_generator.py:452-454) fused
+ * into the PA forward: x [B,S,2] holds the unquantised generator output (dpd_gen_absmax_pass stage 3)
+ * and absmax3 its abs-max; x is quantised in place and y = PA(quantised x). */
+int dpd_quant_pa_forward(float *x, int64_t B, int64_t S, const float *absmax3, const float *coef_re,
+                         const float *coef_im, int K, int M, float *y, void *stream);
+
 /* Gradient of the above w.r.t. x for an upstream gy [B,S-M+1,2]; gx [B,S,2] is overwritten.
  * d|x|/dx at x == 0 is 0, as in torch. */
 int dpd_pa_backward(const float *x, int64_t B, int64_t S, const float *coef_re, const float *coef_im,
                     int K, int M, const float *gy, float *gx, void *stream);
 
-/* Chain iq -> generator -> PA twin (the validation chain of demo/video_demo.py:221-248) on one
- * stream: dpd_out [B,S-5,2] receives the generator output, y [B, S-5-M+1, 2] the PA output.
- * With qat != 0 absmax[0..3] must already hold the four scales (dpd_gen_absmax_pass 0..3). */
+/* Chain iq -> generator -> PA twin (the validation chain of demo/video_demo.py:221-248):
+ * y [B, S-5-M+1, 2] receives the PA output, dpd_out [B,S-5,2] the generator output (optional for
+ * B*(S-5) >= 4096, where the whole chain is one kernel and the generator output stays on chip;
+ * required below that).  With qat != 0 absmax[0..3] must already hold the four scales
+ * (dpd_gen_absmax_pass 0..3).  DPD_ERR_SHAPE if S <= 5 or S-5 < M. */
 int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
                        const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
                        float *dpd_out, float *y, void *stream);

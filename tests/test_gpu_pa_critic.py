@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 import torch
 
-from gpu_util import DEV, T, close, load_golden, sd
+from gpu_util import DEV, T, close, close_q, load_golden, ofdm_rows, sd
 
 pytestmark = pytest.mark.gpu
 
@@ -208,3 +208,52 @@ def test_critic_ragged_sizes_vs_oracle(n, critic_impl):
     for lin in d._layers():
         close(lin.bias.grad, rg[i], rtol=3e-4, atol=1e-5 * float(rg[i].abs().max())); i += 1
         close(lin.weight_orig.grad, rg[i], rtol=3e-4, atol=1e-5 * float(rg[i].abs().max())); i += 1
+
+
+# ------------------------------------------------------------------ fused generator -> PA chain
+@pytest.mark.parametrize("qat", [False, True])
+@pytest.mark.parametrize("shape", [(8, 1029), (5, 901), (3, 2000), (70, 64), (2, 37)])
+def test_chain_fused_vs_modules_vs_oracle(qat, shape):
+    """dpd_pa_chain (one kernel for >= 4096 samples, chunks overlapping by M - 1 generator outputs;
+    two-kernel fallback below) against generator module -> PA module and against the oracle."""
+    from oracle import generator as og, pa as opa
+    from dpd_amd.models import TDNNGeneratorQAT, PADigitalTwin, dpd_pa_chain
+    B, S = shape
+    torch.manual_seed(11)
+    gen = TDNNGeneratorQAT()
+    with torch.no_grad():
+        for fc in (gen.fc1, gen.fc2, gen.fc3):
+            fc.bias.uniform_(-0.1, 0.1)
+    params = {k: v.clone() for k, v in gen.state_dict().items() if k in og.PARAM_KEYS}
+    gen = gen.to(DEV).eval()
+    gen.qat_enabled = qat
+    pa = PADigitalTwin().to(DEV)
+    pa.set_temperature_state("hot")
+    iq = ofdm_rows(B, S, seed=B * 77 + S)
+    with torch.no_grad():
+        d_mod = gen(iq.to(DEV))
+        y_mod = pa(d_mod, add_noise=False)
+    d_f, y_f = dpd_pa_chain(gen, pa, iq.to(DEV))
+    none, y_only = dpd_pa_chain(gen, pa, iq.to(DEV), return_dpd=False)
+    assert none is None
+    assert d_f.shape == d_mod.shape and y_f.shape == y_mod.shape
+    # same arithmetic in both paths
+    cmp = close_q if qat else close
+    cmp(d_f, d_mod.cpu().numpy())
+    scale = float(y_mod.abs().max())
+    close(y_f, y_mod.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale if not qat else 2e-4 * scale)
+    close(y_only, y_f.cpu().numpy(), rtol=0, atol=0)
+    # oracle
+    d_ref = og.gen_forward(iq, params, qat=qat)
+    cre, cim = pa.pa_model.coeffs_real.cpu(), pa.pa_model.coeffs_imag.cpu()
+    y_ref = opa.volterra_forward(d_ref.detach(), cre, cim)
+    close(y_f, y_ref.numpy(), rtol=1e-4, atol=(3e-6 if not qat else 3e-4) * scale)
+
+
+def test_chain_errors():
+    from dpd_amd.models import TDNNGeneratorQAT, PADigitalTwin, dpd_pa_chain
+    gen, pa = TDNNGeneratorQAT().to(DEV).eval(), PADigitalTwin().to(DEV)
+    with pytest.raises(ValueError):
+        dpd_pa_chain(gen, pa, torch.zeros(2, 5, 2, device=DEV))
+    with pytest.raises(ValueError):
+        dpd_pa_chain(gen, pa, torch.zeros(2, 9, 2, device=DEV))     # 4 generator outputs < 5 PA taps
