@@ -37,6 +37,9 @@ PROTOTYPES = {
     "dpd_critic_gp": [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p],
     "dpd_spectral_stats": [c_p, c_p, c_l, c_l, c_p, c_p, c_p],
     "dpd_spectral_backward": [c_p, c_p, c_l, c_l, c_p, c_p, c_p, c_p],
+    "dpd_spectral_rowdb": [c_p, c_l, c_l, c_p, c_p, c_p],
+    "dpd_spectral_loss_final": [c_p, c_l, c_f, c_f, c_f, c_p, c_p],
+    "dpd_spectral_terms_backward": [c_p, c_p, c_p, c_l, c_l, c_p, c_p],
     "dpd_quantize_fixed": [c_p, c_l, c_f, c_i, c_i, c_i, c_p, c_p],
     "dpd_fake_quantize_dynamic": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p],
     "dpd_q88_infer": [c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],

@@ -139,6 +139,284 @@ __global__ __launch_bounds__(TPB) void k_spectral_bwd(const float2 *__restrict__
     }
 }
 
+
+// ------------------------------------------------------------------ L = 1024: one wave per row, FFT in registers
+// 1024 = 16 x 16 x 4.  Lane l holds x[64 m + l], m = 0..15 (coalesced loads).  Forward transform:
+//   S1 16-point DFT over m -> A[k1];  T1 A[k1] *= W1024^(l k1);
+//   P1 through LDS: lane (k1', a') = (l >> 2, l & 3) takes A_{4p + a'}[k1'], p = 0..15;
+//   S2 16-point DFT over p -> C[q];   T2 C[q] *= W64^(a' q);
+//   P2 through LDS: lane (k1', u) takes C_{a}[4 qi + u] for qi, a = 0..3;
+//   S3 4-point DFT over a -> X[k1' + 16 (4 qi + u) + 256 r] in register 4 qi + r.
+// The DFT matrix is symmetric, so running the same stages in reverse order (S3, P2^-1, T2, S2, P1^-1, T1, S1)
+// transforms a vector held in the output layout back into the input layout: that is the second transform of
+// the backward pass, and its result lands where the coalesced store wants it.  All LDS traffic is wave-private.
+namespace w1024 {
+
+constexpr int ROWS_PER_BLOCK = 4;          // waves
+constexpr int PITCH = 68;                  // complex words per k1 row of the transposition buffer (136 = 8 mod 32 banks)
+constexpr int BUF = 16 * PITCH;
+
+struct cpx {
+    float x, y;
+};
+DEV cpx operator+(cpx a, cpx b) { return {a.x + b.x, a.y + b.y}; }
+DEV cpx operator-(cpx a, cpx b) { return {a.x - b.x, a.y - b.y}; }
+DEV cpx cmul(cpx a, cpx b) { return {a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x}; }
+DEV cpx mul_mi(cpx a) { return {a.y, -a.x}; }     // a * (-i)
+
+DEV void fft4(cpx &v0, cpx &v1, cpx &v2, cpx &v3) {
+    const cpx t0 = v0 + v2, t1 = v0 - v2, t2 = v1 + v3, t3 = mul_mi(v1 - v3);
+    v0 = t0 + t2;
+    v1 = t1 + t3;
+    v2 = t0 - t2;
+    v3 = t1 - t3;
+}
+
+// natural-order 16-point DFT of v[0..15] (index m = 4a + b -> k = c + 4d)
+DEV void fft16(cpx (&v)[16]) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) fft4(v[b], v[4 + b], v[8 + b], v[12 + b]);      // v[4c + b] = y[b][c]
+    const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+    const cpx w1 = {c1, -s1}, w2 = {h, -h}, w3 = {s1, -c1}, w6 = {-h, -h}, w9 = {-c1, s1};
+    v[4 * 1 + 1] = cmul(v[4 * 1 + 1], w1);
+    v[4 * 2 + 1] = cmul(v[4 * 2 + 1], w2);
+    v[4 * 3 + 1] = cmul(v[4 * 3 + 1], w3);
+    v[4 * 1 + 2] = cmul(v[4 * 1 + 2], w2);
+    v[4 * 2 + 2] = mul_mi(v[4 * 2 + 2]);
+    v[4 * 3 + 2] = cmul(v[4 * 3 + 2], w6);
+    v[4 * 1 + 3] = cmul(v[4 * 1 + 3], w3);
+    v[4 * 2 + 3] = cmul(v[4 * 2 + 3], w6);
+    v[4 * 3 + 3] = cmul(v[4 * 3 + 3], w9);
+    cpx o[16];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        cpx a0 = v[4 * c + 0], a1 = v[4 * c + 1], a2 = v[4 * c + 2], a3 = v[4 * c + 3];
+        fft4(a0, a1, a2, a3);
+        o[c] = a0;
+        o[c + 4] = a1;
+        o[c + 8] = a2;
+        o[c + 12] = a3;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) v[k] = o[k];
+}
+
+// Twiddle tables in LDS, shared by the block: t1[k][l] = W1024^(l k) (read by lane l: conflict-free),
+// t2[q][a] = W64^(a q).  Keeping them out of the register file is worth a resident wave per SIMD.
+struct Twiddles {
+    const float2 *t1, *t2;
+};
+DEV void make_tw(float2 *t1, float2 *t2) {
+    for (int i = threadIdx.x; i < 1024; i += ROWS_PER_BLOCK * 64) {
+        float s, c;
+        sincospif(-2.0f * (float)((i & 63) * (i >> 6)) / 1024.0f, &s, &c);
+        t1[i] = make_float2(c, s);
+    }
+    for (int i = threadIdx.x; i < 64; i += ROWS_PER_BLOCK * 64) {
+        float s, c;
+        sincospif(-2.0f * (float)((i & 3) * (i >> 2)) / 64.0f, &s, &c);
+        t2[i] = make_float2(c, s);
+    }
+    __syncthreads();
+}
+DEV cpx tw1(const Twiddles &t, int k, int lane) {
+    const float2 w = t.t1[64 * k + lane];
+    return {w.x, w.y};
+}
+DEV cpx tw2(const Twiddles &t, int q, int lane) {
+    const float2 w = t.t2[4 * q + (lane & 3)];
+    return {w.x, w.y};
+}
+
+DEV void forward(cpx (&v)[16], const Twiddles &tw, float2 *buf, int lane) {
+    const int k1 = lane >> 2, a = lane & 3;
+    fft16(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw1(tw, k, lane));
+#pragma unroll
+    for (int k = 0; k < 16; ++k) buf[k * PITCH + lane] = make_float2(v[k].x, v[k].y);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const float2 t = buf[k1 * PITCH + 4 * p + a];
+        v[p] = {t.x, t.y};
+    }
+    __builtin_amdgcn_wave_barrier();
+    fft16(v);
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw2(tw, q, lane));
+#pragma unroll
+    for (int q = 0; q < 16; ++q) buf[k1 * PITCH + 4 * q + a] = make_float2(v[q].x, v[q].y);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) {
+            const float2 t = buf[k1 * PITCH + 4 * (4 * qi + a) + aa];   // u == a: this lane's residue of q
+            v[4 * qi + aa] = {t.x, t.y};
+        }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) fft4(v[4 * qi], v[4 * qi + 1], v[4 * qi + 2], v[4 * qi + 3]);
+}
+
+// the same stages in reverse order: output layout -> input layout
+DEV void transposed(cpx (&v)[16], const Twiddles &tw, float2 *buf, int lane) {
+    const int k1 = lane >> 2, a = lane & 3;
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi) fft4(v[4 * qi], v[4 * qi + 1], v[4 * qi + 2], v[4 * qi + 3]);
+#pragma unroll
+    for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+        for (int aa = 0; aa < 4; ++aa) buf[k1 * PITCH + 4 * (4 * qi + a) + aa] = make_float2(v[4 * qi + aa].x, v[4 * qi + aa].y);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+        const float2 t = buf[k1 * PITCH + 4 * q + a];
+        v[q] = {t.x, t.y};
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int q = 1; q < 16; ++q) v[q] = cmul(v[q], tw2(tw, q, lane));
+    fft16(v);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) buf[k1 * PITCH + 4 * p + a] = make_float2(v[p].x, v[p].y);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float2 t = buf[k * PITCH + lane];
+        v[k] = {t.x, t.y};
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw1(tw, k, lane));
+    fft16(v);
+}
+
+// bit (4 qi + r) of word b: band b contains the bin this lane holds in register 4 qi + r
+DEV void band_bits(unsigned (&bits)[3], const uint8_t *__restrict__ band, int lane) {
+    const int k1 = lane >> 2, u = lane & 3;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        bits[b] = 0u;
+#pragma unroll
+        for (int qi = 0; qi < 4; ++qi)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k1 + 16 * (4 * qi + u) + 256 * r;
+                bits[b] |= (band[b * 1024 + k] ? 1u : 0u) << (4 * qi + r);
+            }
+    }
+}
+
+__global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_stats(const float2 *__restrict__ pred, const float2 *__restrict__ target,
+                                                              int64_t B, const uint8_t *__restrict__ band,
+                                                              float *__restrict__ stats) {
+    __shared__ float2 lds[ROWS_PER_BLOCK][BUF];
+    __shared__ float2 s_t1[1024], s_t2[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    make_tw(s_t1, s_t2);
+    const Twiddles tw{s_t1, s_t2};
+    unsigned bits[3];
+    band_bits(bits, band, lane);
+    for (int64_t b = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; b < B; b += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+        const float2 *p = pred + b * 1024;
+        cpx v[16];
+        float s_abs = 0.f, s_err = 0.f, s_ref = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float2 x = p[64 * m + lane];
+            v[m] = {x.x, x.y};
+            if (target) {
+                const float2 t = target[b * 1024 + 64 * m + lane];
+                const float dx = x.x - t.x, dy = x.y - t.y;
+                s_abs += fabsf(dx) + fabsf(dy);
+                s_err += dx * dx + dy * dy;
+                s_ref += t.x * t.x + t.y * t.y;
+            }
+        }
+        forward(v, tw, lds[wave], lane);
+        float pm = 0.f, pl = 0.f, pu = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pw = (v[i].x * v[i].x + v[i].y * v[i].y) * (1.0f / 1024.0f);
+            pm += ((bits[0] >> i) & 1u) ? pw : 0.f;
+            pl += ((bits[1] >> i) & 1u) ? pw : 0.f;
+            pu += ((bits[2] >> i) & 1u) ? pw : 0.f;
+        }
+        s_abs = wave_sum(s_abs);
+        s_err = wave_sum(s_err);
+        s_ref = wave_sum(s_ref);
+        pm = wave_sum(pm);
+        pl = wave_sum(pl);
+        pu = wave_sum(pu);
+        if (lane == 0) {
+            float *o = stats + b * 8;
+            o[0] = s_abs; o[1] = s_err; o[2] = s_ref; o[3] = pm; o[4] = pl; o[5] = pu; o[6] = 0.f; o[7] = 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_bwd(const float2 *__restrict__ pred, const float2 *__restrict__ target,
+                                                            int64_t B, const uint8_t *__restrict__ band,
+                                                            const float *__restrict__ gstats, float2 *__restrict__ dpred) {
+    __shared__ float2 lds[ROWS_PER_BLOCK][BUF];
+    __shared__ float2 s_t1[1024], s_t2[64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    make_tw(s_t1, s_t2);
+    const Twiddles tw{s_t1, s_t2};
+    unsigned bits[3];
+    band_bits(bits, band, lane);
+    for (int64_t b = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; b < B; b += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
+        const float2 *p = pred + b * 1024;
+        const float *gs = gstats + b * 8;
+        const float g_abs = gs[0], g_err = gs[1], g_m = gs[3], g_l = gs[4], g_u = gs[5];
+        const bool need_fft = (g_m != 0.f) || (g_l != 0.f) || (g_u != 0.f);   // wave-uniform
+        cpx x[16], v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float2 t = p[64 * m + lane];
+            x[m] = {t.x, t.y};
+            v[m] = x[m];
+        }
+        if (need_fft) {
+            forward(v, tw, lds[wave], lane);
+            // Y = conj(w X), then the transposed transform: IDFT_unnormalised(w X) = conj(F conj(w X))
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float w = (((bits[0] >> i) & 1u) ? g_m : 0.f) + (((bits[1] >> i) & 1u) ? g_l : 0.f) +
+                                (((bits[2] >> i) & 1u) ? g_u : 0.f);
+                v[i] = {w * v[i].x, -w * v[i].y};
+            }
+            transposed(v, tw, lds[wave], lane);
+        }
+        const float c2 = 2.0f / 1024.0f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            float gx = 0.f, gy = 0.f;
+            if (need_fft) {
+                gx = c2 * v[m].x;
+                gy = -c2 * v[m].y;
+            }
+            if (target) {
+                const float2 t = target[b * 1024 + 64 * m + lane];
+                const float dx = x[m].x - t.x, dy = x[m].y - t.y;
+                gx += g_abs * (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f)) + 2.f * g_err * dx;
+                gy += g_abs * (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f)) + 2.f * g_err * dy;
+            }
+            dpred[b * 1024 + 64 * m + lane] = make_float2(gx, gy);
+        }
+    }
+}
+
+int grid_for_rows(int64_t B) {
+    int64_t blocks = (B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    if (blocks > 256 * 3) blocks = 256 * 3;      // 43 KB of LDS per block: three resident blocks per CU
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace w1024
+
 int check_len(int64_t L, int *log2n) {
     int l2 = 0;
     while ((1ll << l2) < L) ++l2;
@@ -148,6 +426,135 @@ int check_len(int64_t L, int *log2n) {
 
 }  // namespace
 
+// ------------------------------------------------------------------ loss arithmetic on the row statistics
+// SpectralLoss.forward (utils/spectral_loss.py:209-257) after the per-row statistics, in three tiny kernels so
+// that a data-parallel caller can all-reduce the five sums in between:
+//   rowdb:  per row (EVM_dB, ACPR_lower_dB, ACPR_upper_dB, NMSE_dB); sums = (sum|p-t|, sum EVM_dB, sum lower,
+//           sum upper, sum NMSE_dB, rows) over the rows, in a fixed order (one workgroup, fp64 partials)
+//   final:  total = w_l1 L1 + w_evm clamp((mean EVM_dB + 40)/40, 0, 2) + w_acpr clamp((max(mean lo, mean up) + 50)/50, 0, 2)
+//           and the derivative of total w.r.t. the first four sums
+//   terms_backward: d total / d statistics of every row (chain rule through the dB conversions)
+namespace terms {
+
+constexpr float LN10 = 2.302585092994046f;
+
+struct RowDb {
+    float evm, lo, up, nmse;
+};
+DEV RowDb row_db(const float *st, float n) {
+    RowDb r;
+    const float ref_power = fmaxf(st[2] / n, 1e-10f);
+    const float evm = sqrtf((st[1] / n) / ref_power);
+    r.evm = 20.f * log10f(evm + 1e-10f);
+    const float mainp = fmaxf(st[3], 1e-10f);
+    r.lo = 10.f * log10f(st[4] / mainp + 1e-10f);
+    r.up = 10.f * log10f(st[5] / mainp + 1e-10f);
+    r.nmse = 10.f * log10f(st[1] / fmaxf(st[2], 1e-10f) + 1e-10f);
+    return r;
+}
+
+__global__ __launch_bounds__(1024) void k_rowdb(const float *__restrict__ stats, int64_t B, float n,
+                                                float *__restrict__ rowdb, float *__restrict__ sums) {
+    __shared__ double red[16][5];
+    double a[5] = {0, 0, 0, 0, 0};
+    for (int64_t b = threadIdx.x; b < B; b += 1024) {
+        const float *st = stats + b * 8;
+        const RowDb r = row_db(st, n);
+        if (rowdb) {
+            float *o = rowdb + b * 4;
+            o[0] = r.evm; o[1] = r.lo; o[2] = r.up; o[3] = r.nmse;
+        }
+        a[0] += st[0]; a[1] += r.evm; a[2] += r.lo; a[3] += r.up; a[4] += r.nmse;
+    }
+#pragma unroll
+    for (int i = 0; i < 5; ++i) a[i] = wave_sum_d(a[i]);
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 5; ++i) red[threadIdx.x >> 6][i] = a[i];
+    __syncthreads();
+    if (threadIdx.x < 5) {
+        double t = 0;
+        for (int w = 0; w < 16; ++w) t += red[w][threadIdx.x];
+        sums[threadIdx.x] = (float)t;
+    }
+    if (threadIdx.x == 5) sums[5] = (float)B;
+    if (threadIdx.x == 6) sums[6] = 0.f;
+    if (threadIdx.x == 7) sums[7] = 0.f;
+}
+
+// out[0..3] = total, L1, evm term, acpr term; out[4..7] = d total / d sums[0..3]
+__global__ void k_final(const float *__restrict__ sums, float n, float w_l1, float w_evm, float w_acpr,
+                        float *__restrict__ out) {
+    if (threadIdx.x != 0) return;
+    const float Bg = sums[5];
+    const float l1 = sums[0] / (Bg * n * 2.f);
+    const float evm_mean = sums[1] / Bg, lo = sums[2] / Bg, up = sums[3] / Bg;
+    const float ev = (evm_mean + 40.f) / 40.f, evm_term = fminf(fmaxf(ev, 0.f), 2.f);
+    const float mx = fmaxf(lo, up), ac = (mx + 50.f) / 50.f, acpr_term = fminf(fmaxf(ac, 0.f), 2.f);
+    out[0] = w_l1 * l1 + w_evm * evm_term + w_acpr * acpr_term;
+    out[1] = l1;
+    out[2] = evm_term;
+    out[3] = acpr_term;
+    out[4] = w_l1 / (Bg * n * 2.f);
+    out[5] = (ev >= 0.f && ev <= 2.f) ? w_evm / (40.f * Bg) : 0.f;          // clamp passes gradient on [min, max]
+    const float ga = (ac >= 0.f && ac <= 2.f) ? w_acpr / (50.f * Bg) : 0.f;
+    out[6] = lo > up ? ga : (lo < up ? 0.f : 0.5f * ga);                     // a tie splits evenly, as torch.maximum
+    out[7] = up > lo ? ga : (up < lo ? 0.f : 0.5f * ga);
+}
+
+__global__ __launch_bounds__(256) void k_terms_bwd(const float *__restrict__ stats, const float *__restrict__ coef,
+                                                   const float *__restrict__ gscale, int64_t B, float n,
+                                                   float *__restrict__ gstats) {
+    const float g = gscale ? gscale[0] : 1.f;
+    const float c0 = g * coef[0], c1 = g * coef[1], c2 = g * coef[2], c3 = g * coef[3];
+    for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < B; b += (int64_t)gridDim.x * 256) {
+        const float *st = stats + b * 8;
+        float *o = gstats + b * 8;
+        // EVM_dB = 20 log10(e + 1e-10), e = sqrt(r), r = (s1/n) / max(s2/n, 1e-10)
+        const float ref_power = fmaxf(st[2] / n, 1e-10f);
+        const float r = (st[1] / n) / ref_power, e = sqrtf(r);
+        const float d_evm = e > 0.f ? 20.f / (LN10 * (e + 1e-10f)) * (0.5f / e) / (n * ref_power) : 0.f;
+        const float mainp = fmaxf(st[3], 1e-10f);
+        const float rl = st[4] / mainp, ru = st[5] / mainp;
+        const float dl = 10.f / (LN10 * (rl + 1e-10f)), du = 10.f / (LN10 * (ru + 1e-10f));
+        const float pass = st[3] >= 1e-10f ? 1.f : 0.f;
+        o[0] = c0;
+        o[1] = c1 * d_evm;
+        o[2] = 0.f;                                   // the reference signal carries no gradient
+        o[3] = -pass * (c2 * dl * rl + c3 * du * ru) / mainp;
+        o[4] = c2 * dl / mainp;
+        o[5] = c3 * du / mainp;
+        o[6] = 0.f;
+        o[7] = 0.f;
+    }
+}
+
+}  // namespace terms
+
+extern "C" int dpd_spectral_rowdb(const float *stats, int64_t B, int64_t L, float *rowdb, float *sums, void *stream) {
+    DPD_REQUIRE(stats && sums && B >= 0 && L >= 1, DPD_ERR_INVALID_ARG, "spectral_rowdb: bad argument");
+    hipLaunchKernelGGL(terms::k_rowdb, dim3(1), dim3(1024), 0, as_stream(stream), stats, B, (float)L, rowdb, sums);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+extern "C" int dpd_spectral_loss_final(const float *sums, int64_t L, float w_l1, float w_evm, float w_acpr, float *out,
+                                       void *stream) {
+    DPD_REQUIRE(sums && out && L >= 1, DPD_ERR_INVALID_ARG, "spectral_loss_final: bad argument");
+    hipLaunchKernelGGL(terms::k_final, dim3(1), dim3(64), 0, as_stream(stream), sums, (float)L, w_l1, w_evm, w_acpr, out);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+extern "C" int dpd_spectral_terms_backward(const float *stats, const float *coef, const float *gscale, int64_t B,
+                                           int64_t L, float *gstats, void *stream) {
+    DPD_REQUIRE(stats && coef && gstats && B >= 0 && L >= 1, DPD_ERR_INVALID_ARG, "spectral_terms_backward: bad argument");
+    if (B == 0) return DPD_OK;
+    hipLaunchKernelGGL(terms::k_terms_bwd, dim3(grid_for(B, 256)), dim3(256), 0, as_stream(stream), stats, coef, gscale, B,
+                       (float)L, gstats);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
 extern "C" int dpd_spectral_stats(const float *pred, const float *target, int64_t B, int64_t L, const uint8_t *band,
                                   float *stats, void *stream) {
     DPD_REQUIRE(pred && stats && (band || target), DPD_ERR_INVALID_ARG, "spectral_stats: null pointer");
@@ -156,6 +563,13 @@ extern "C" int dpd_spectral_stats(const float *pred, const float *target, int64_
     DPD_REQUIRE(!band || check_len(L, &log2n), DPD_ERR_INVALID_ARG,
                 "spectral_stats: row length %lld is not a power of two in 2..4096", (long long)L);
     if (B <= 0) return DPD_OK;
+    if (band && L == 1024) {
+        hipLaunchKernelGGL(w1024::k_stats, dim3(w1024::grid_for_rows(B)), dim3(w1024::ROWS_PER_BLOCK * 64), 0,
+                           as_stream(stream), reinterpret_cast<const float2 *>(pred),
+                           reinterpret_cast<const float2 *>(target), B, band, stats);
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
     const size_t lds = band ? (size_t)(L + L / 2) * sizeof(float2) : 0;
     hipLaunchKernelGGL(k_spectral_stats, dim3((unsigned)B), dim3(TPB), lds, as_stream(stream),
                        reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), L, log2n,
@@ -172,6 +586,13 @@ extern "C" int dpd_spectral_backward(const float *pred, const float *target, int
     DPD_REQUIRE(!band || check_len(L, &log2n), DPD_ERR_INVALID_ARG,
                 "spectral_backward: row length %lld is not a power of two in 2..4096", (long long)L);
     if (B <= 0) return DPD_OK;
+    if (band && L == 1024) {
+        hipLaunchKernelGGL(w1024::k_bwd, dim3(w1024::grid_for_rows(B)), dim3(w1024::ROWS_PER_BLOCK * 64), 0,
+                           as_stream(stream), reinterpret_cast<const float2 *>(pred),
+                           reinterpret_cast<const float2 *>(target), B, band, gstats, reinterpret_cast<float2 *>(dpred));
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
     const size_t lds = band ? (size_t)(L + L / 2) * sizeof(float2) : 0;
     hipLaunchKernelGGL(k_spectral_bwd, dim3((unsigned)B), dim3(TPB), lds, as_stream(stream),
                        reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), L, log2n,

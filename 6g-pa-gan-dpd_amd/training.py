@@ -108,20 +108,21 @@ class Stage2Step:
         return total / self.dp.world, info
 
     def _generator_loss(self, fake, target, cond):
-        from .utils.spectral_loss import _loss_terms
+        from .utils.spectral_loss import spectral_total
         dp, sl = self.dp, self.sl
         g_adv, _ = self.wl.generator_loss(self.disc, fake, cond, sync_info=False)
-        l1, evm_db, lo_db, up_db, _ = _loss_terms(fake, target, sl.sample_rate, sl.channel_bw, sl.adjacent_offset)
-        B = fake.shape[0] * dp.world
-        sums = dp.global_sum(torch.stack([l1 / dp.world, evm_db.sum() / B, lo_db.sum() / B, up_db.sum() / B,
-                                          g_adv / dp.world]))
-        l1_g, evm_mean, lo_mean, up_mean, adv_g = sums.unbind(0)
-        evm_loss = torch.clamp((evm_mean + 40) / 40, 0, 2)
-        acpr_loss = torch.clamp((torch.max(lo_mean, up_mean) + 50) / 50, 0, 2)
-        spectral = sl.l1_weight * l1_g + sl.evm_weight * evm_loss + sl.acpr_weight * acpr_loss
-        total = self.w_adv * adv_g + self.w_l1 * l1_g + spectral
-        return total, dict(g_total=total.detach(), g_adv=adv_g.detach(), recon=l1_g.detach(), spectral=spectral.detach(),
-                           evm=evm_loss.detach(), acpr=acpr_loss.detach())
+        adv_g = dp.global_sum(g_adv / dp.world)
+
+        def sum_fn(sums):                      # row sums and row count of all ranks -> terms of the global batch
+            dp.sum_(sums)
+        # the reconstruction term w_l1 * L1 rides on the spectral loss's own L1 (one pass over the samples)
+        fused, l1_g, evm_loss, acpr_loss = spectral_total(fake, target, sl.sample_rate, sl.channel_bw, sl.adjacent_offset,
+                                                         sl.l1_weight + self.w_l1, sl.evm_weight, sl.acpr_weight,
+                                                         sum_fn if dp.enabled else None)
+        total = self.w_adv * adv_g + fused
+        spectral = fused.detach() - self.w_l1 * l1_g
+        return total, dict(g_total=total.detach(), g_adv=adv_g.detach(), recon=l1_g, spectral=spectral,
+                           evm=evm_loss, acpr=acpr_loss)
 
     def __call__(self, iq: torch.Tensor, target: torch.Tensor, cond: torch.Tensor, alphas=None) -> Dict[str, torch.Tensor]:
         gen, disc, dp = self.gen, self.disc, self.dp

@@ -4,8 +4,8 @@ create_spectral_loss :342-354) on top of libdpd_hip.so.
 
 All per-sample work (error sums, the row FFT, band powers, and their gradient through an inverse
 transform) runs in csrc/spectral.hip and produces six statistics per row; the scalar arithmetic on
-the [B] statistics (dB conversions, clamps, means, max) is plain torch on the device, with
-autograd carrying the gradient back to the statistics.  The reference signal is treated as a
+the [B] statistics (dB conversions, clamps, means, max) is plain torch on the device for the
+stand-alone metrics and three small kernels for SpectralLoss itself (spectral_total).  The reference signal is treated as a
 constant (no gradient), as in every use the reference makes of these functions.
 """
 from typing import Dict, Optional, Tuple
@@ -59,6 +59,55 @@ class _RowStatsFn(torch.autograd.Function):
         L.call("dpd_spectral_backward", L.fptr(p), L.fptr(t if has_t else None), B, n,
                L.fptr(band if has_band else None, torch.uint8), L.fptr(L.as_f32(gstats)), L.fptr(dpred), L.stream())
         return dpred, None, None
+
+
+class _SpectralTotalFn(torch.autograd.Function):
+    """(total, l1, evm_term, acpr_term) of SpectralLoss.forward in five launches: row statistics, dB
+    conversion + row sums, the scalar terms (forward); d total / d statistics, then the statistics'
+    gradient through the inverse transform (backward).  `sum_fn(t)` (optional) all-reduces the
+    six-entry sums tensor in place across data-parallel ranks, which makes every term that of the
+    global batch.  Only `total` carries a gradient."""
+
+    @staticmethod
+    def forward(ctx, pred, target, band, w_l1, w_evm, w_acpr, sum_fn):
+        L.need_gpu(pred, target, band)
+        p, t = L.as_f32(pred), L.as_f32(target)
+        B, n = p.shape[0], p.shape[1]
+        if n & (n - 1) or n < 2 or n > 4096:
+            raise NotImplementedError(f"ACPR on the HIP path needs a power-of-two row length in 2..4096, got {n}")
+        st = L.stream()
+        stats = torch.empty(B, 8, dtype=torch.float32, device=p.device)
+        sums = torch.empty(8, dtype=torch.float32, device=p.device)
+        out = torch.empty(8, dtype=torch.float32, device=p.device)
+        L.call("dpd_spectral_stats", L.fptr(p), L.fptr(t), B, n, L.fptr(band, torch.uint8), L.fptr(stats), st)
+        L.call("dpd_spectral_rowdb", L.fptr(stats), B, n, L.c_p(0), L.fptr(sums), st)
+        if sum_fn is not None:
+            sum_fn(sums)
+        L.call("dpd_spectral_loss_final", L.fptr(sums), n, float(w_l1), float(w_evm), float(w_acpr), L.fptr(out), st)
+        ctx.save_for_backward(p, t, band, stats, out)
+        total, l1, evm, acpr = out[0], out[1], out[2], out[3]
+        ctx.mark_non_differentiable(l1, evm, acpr)
+        return total, l1, evm, acpr
+
+    @staticmethod
+    def backward(ctx, g_total, _g1, _g2, _g3):
+        p, t, band, stats, out = ctx.saved_tensors
+        B, n = p.shape[0], p.shape[1]
+        st = L.stream()
+        gstats = torch.empty_like(stats)
+        g = L.as_f32(g_total).reshape(1)
+        L.call("dpd_spectral_terms_backward", L.fptr(stats), L.fptr(out[4:]), L.fptr(g), B, n, L.fptr(gstats), st)
+        dpred = torch.empty_like(p)
+        L.call("dpd_spectral_backward", L.fptr(p), L.fptr(t), B, n, L.fptr(band, torch.uint8), L.fptr(gstats),
+               L.fptr(dpred), st)
+        return dpred, None, None, None, None, None, None
+
+
+def spectral_total(pred, target, sample_rate, channel_bw, adjacent_offset, w_l1, w_evm, w_acpr, sum_fn=None):
+    """w_l1 * L1 + w_evm * EVM term + w_acpr * ACPR term and the three terms (0-d device tensors)."""
+    p, t = _as_iq(pred), _as_iq(target)
+    band = band_masks(p.shape[1], sample_rate, channel_bw, adjacent_offset, p.device)
+    return _SpectralTotalFn.apply(p, t.detach(), band, w_l1, w_evm, w_acpr, sum_fn)
 
 
 def _as_iq(x: torch.Tensor) -> torch.Tensor:
@@ -127,10 +176,9 @@ class SpectralLoss(nn.Module):
         self.l1_loss = nn.L1Loss()
 
     def forward(self, predicted: torch.Tensor, target: torch.Tensor, return_components: bool = False):
-        l1, evm_db, lo_db, up_db, _ = _loss_terms(predicted, target, self.sample_rate, self.channel_bw, self.adjacent_offset)
-        evm_loss = torch.clamp((evm_db.mean() + 40) / 40, 0, 2)
-        acpr_loss = torch.clamp((torch.max(lo_db.mean(), up_db.mean()) + 50) / 50, 0, 2)
-        total = self.l1_weight * l1 + self.evm_weight * evm_loss + self.acpr_weight * acpr_loss
+        total, l1, evm_loss, acpr_loss = spectral_total(predicted, target, self.sample_rate, self.channel_bw,
+                                                        self.adjacent_offset, self.l1_weight, self.evm_weight,
+                                                        self.acpr_weight)
         if return_components:
             return total, {"l1": l1, "evm": evm_loss, "acpr": acpr_loss}
         return total

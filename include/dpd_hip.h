@@ -175,6 +175,21 @@ int dpd_spectral_stats(const float *pred, const float *target, int64_t B, int64_
 int dpd_spectral_backward(const float *pred, const float *target, int64_t B, int64_t L,
                           const uint8_t *band, const float *gstats, float *dpred, void *stream);
 
+/* The loss arithmetic of SpectralLoss.forward (utils/spectral_loss.py:209-257) on the row statistics,
+ * split so that a data-parallel caller can all-reduce `sums` between the first two calls.
+ * dpd_spectral_rowdb: rowdb [B,4] (optional) = per-row EVM_dB, ACPR_lower_dB, ACPR_upper_dB, NMSE_dB
+ * (compute_evm :24-64, compute_acpr :67-132, compute_nmse :135-167); sums[8] = (sum|p-t|, sum EVM_dB,
+ * sum lower, sum upper, sum NMSE_dB, B, 0, 0), reduced in a fixed order.
+ * dpd_spectral_loss_final: out[8] = (total, L1, EVM term, ACPR term, d total / d sums[0..3]) with
+ * sums[5] as the (global) row count.
+ * dpd_spectral_terms_backward: gstats [B,8] = gscale[0] (device scalar, NULL = 1) * d total / d stats,
+ * the input of dpd_spectral_backward; coef = out + 4. */
+int dpd_spectral_rowdb(const float *stats, int64_t B, int64_t L, float *rowdb, float *sums, void *stream);
+int dpd_spectral_loss_final(const float *sums, int64_t L, float w_l1, float w_evm, float w_acpr, float *out,
+                            void *stream);
+int dpd_spectral_terms_backward(const float *stats, const float *coef, const float *gscale, int64_t B,
+                                int64_t L, float *gstats, void *stream);
+
 /* ---------------------------------------------------------------- fixed point ----------- */
 
 /* quantize_to_fixed_point / fake_quantize (utils/quantization.py:88-161): q = clamp(rint(x*scale),
