@@ -32,6 +32,8 @@ PROTOTYPES = {
     "dpd_pa_backward": [c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "dpd_quant_pa_forward": [c_p, c_l, c_l, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "dpd_gen_pa_forward": [c_p, c_l, c_l, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
+    "dpd_critic_sn_forward": [c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p],
+    "dpd_critic_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p],
     "dpd_critic_forward": [c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p],
     "dpd_critic_backward": [c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p],
     "dpd_critic_gp": [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p],

@@ -48,6 +48,42 @@ class _SNLinearCore(nn.Module):
         return w / sigma
 
 
+def _ptr_array(tensors):
+    import ctypes
+    return (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _SNFlatFn(torch.autograd.Function):
+    """wb[2945] = [W1/sigma1 | b1 | ... | W4/sigma4 | b4] for four spectrally normalised layers: one
+    launch forward (power iteration in place on the u, v buffers when `power_iteration`), one backward."""
+
+    @staticmethod
+    def forward(ctx, power_iteration, eps, us, vs, *wbs):
+        ws, bs = [L.as_f32(t) for t in wbs[0::2]], [L.as_f32(t) for t in wbs[1::2]]
+        L.need_gpu(*ws)
+        dev = ws[0].device
+        wb = torch.empty(L.CRITIC_NPARAM, dtype=torch.float32, device=dev)
+        uv = torch.empty(229, dtype=torch.float32, device=dev)
+        sigma = torch.empty(4, dtype=torch.float32, device=dev)
+        L.call("dpd_critic_sn_forward", _ptr_array(ws), _ptr_array(bs), _ptr_array(us), _ptr_array(vs),
+               int(power_iteration), float(eps), L.fptr(wb), L.fptr(uv), L.fptr(sigma), L.stream())
+        ctx.save_for_backward(uv, sigma, *ws)
+        return wb
+
+    @staticmethod
+    def backward(ctx, gwb):
+        uv, sigma, *ws = ctx.saved_tensors
+        g = torch.empty(L.CRITIC_NPARAM, dtype=torch.float32, device=uv.device)
+        L.call("dpd_critic_sn_backward", _ptr_array(ws), L.fptr(L.as_f32(gwb)), L.fptr(uv), L.fptr(sigma), L.fptr(g),
+               L.stream())
+        out, off = [], 0
+        for n in _SIZES:
+            out.append(g[off:off + n])
+            off += n
+        shaped = [o.view_as(ws[i // 2]) if i % 2 == 0 else o for i, o in enumerate(out)]
+        return (None, None, None, None, *shaped)
+
+
 class SpectralNormLinear(nn.Module):
     def __init__(self, in_features: int, out_features: int, bias: bool = True):
         super().__init__()
@@ -179,8 +215,15 @@ class Discriminator(nn.Module):
         when training); differentiable w.r.t. weight_orig / bias."""
         if self.input_dim != 4 or list(self.hidden_dims) != [64, 32, 16]:
             raise NotImplementedError("the HIP critic is built for 4 -> 64 -> 32 -> 16 -> 1 (the reference default)")
+        layers = list(self._layers())
+        if all(isinstance(lin, _SNLinearCore) for lin in layers) and layers[0].weight_orig.is_cuda:
+            args = []
+            for lin in layers:
+                args += [lin.weight_orig, lin.bias]
+            return _SNFlatFn.apply(self.training, layers[0].eps, [lin.weight_u for lin in layers],
+                                   [lin.weight_v for lin in layers], *args)
         parts = []
-        for lin in self._layers():
+        for lin in layers:
             w = lin.normalized_weight(self.training) if isinstance(lin, _SNLinearCore) else lin.weight
             parts += [w.reshape(-1), lin.bias]
         return torch.cat(parts)

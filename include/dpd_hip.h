@@ -134,6 +134,21 @@ int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, f
 
 /* ---------------------------------------------------------------- critic ---------------- */
 
+/* Spectral normalisation of the four critic layers (SpectralNormLinear, models/discriminator.py:28-42;
+ * torch.nn.utils.spectral_norm, legacy hook form) in one launch.  w_orig, bias, u, v: host arrays of
+ * four device pointers (layers 4->64, 64->32, 32->16, 16->1).  With power_iteration != 0 (training-mode
+ * forward) u and v are advanced in place by one iteration first.  wb [2945] receives the flat operand of
+ * the critic entry points (W_l / sigma_l and b_l); uv_saved [229] the u, v actually used and sigma [4]
+ * the spectral norms, both needed by the backward. */
+int dpd_critic_sn_forward(const float *const *w_orig, const float *const *bias, float *const *u,
+                          float *const *v, int power_iteration, float eps, float *wb, float *uv_saved,
+                          float *sigma, void *stream);
+
+/* Gradient w.r.t. weight_orig / bias (flat, the layout of wb) from the gradient gwb [2945] w.r.t. wb, with
+ * u, v held constant as in the reference: dW = (G - <G, W/sigma> u v^T) / sigma. */
+int dpd_critic_sn_backward(const float *const *w_orig, const float *gwb, const float *uv_saved,
+                           const float *sigma, float *grads, void *stream);
+
 /* Discriminator.forward (models/discriminator.py:103-136) given the already spectrally
  * normalised weights wb (flat, DPD_CRITIC_NPARAM): score[n] for n < N rows of x [N,2], cond [N,2].
  * score_sum (optional) receives sum_n score[n]. */

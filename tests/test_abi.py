@@ -21,7 +21,7 @@ def declared_symbols():
 def test_header_declares_the_expected_surface():
     syms = declared_symbols()
     for name in ("dpd_gen_forward", "dpd_gen_backward", "dpd_gen_mse_step", "dpd_gen_absmax_pass", "dpd_tap_assembly",
-                 "dpd_pa_forward", "dpd_pa_backward", "dpd_quant_pa_forward", "dpd_gen_pa_forward", "dpd_critic_forward", "dpd_critic_backward",
+                 "dpd_pa_forward", "dpd_pa_backward", "dpd_quant_pa_forward", "dpd_gen_pa_forward", "dpd_critic_sn_forward", "dpd_critic_sn_backward", "dpd_critic_forward", "dpd_critic_backward",
                  "dpd_critic_gp", "dpd_spectral_stats", "dpd_spectral_backward", "dpd_spectral_rowdb", "dpd_spectral_loss_final", "dpd_spectral_terms_backward", "dpd_quantize_fixed",
                  "dpd_fake_quantize_dynamic", "dpd_q88_infer", "dpd_q88_int32_safe", "dpd_workspace_bytes"):
         assert name in syms

@@ -120,7 +120,9 @@ def test_gradient_penalty_and_losses_golden(critic_impl):
         if n.endswith("bias"):
             assert p.grad is None or float(p.grad.abs().max()) == 0.0
         else:
-            close(p.grad, ref, rtol=2e-4, atol=2e-6)
+            # entries are differences G - <G, W/sigma> u v^T of much larger numbers: the fp32 noise of an
+            # entry scales with the largest gradient of the layer, not with the entry itself
+            close(p.grad, ref, rtol=2e-4, atol=2e-6 + 1e-6 * float(np.abs(ref).max()))
     gp2 = compute_gradient_penalty(d, T(g["gp2_real"]), T(g["gp2_fake"]), T(g["gp2_cond"]), dev, alpha=T(g["gp2_alpha"]))
     close(gp2, g["gp2"], rtol=1e-5)
     d.zero_grad()
