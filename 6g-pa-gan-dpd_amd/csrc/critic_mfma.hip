@@ -296,6 +296,9 @@ DEV void combine_rows(float *lds, float *slab_row) {
 }
 
 // ------------------------------------------------------------------------------------- kernels
+#ifndef NOGRAD_WAVES
+#define NOGRAD_WAVES 2      // measured: 3 waves per SIMD (168 registers, ~35 spilled) is 7% slower on the Stage-2 step
+#endif
 __global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__restrict__ x, const float *__restrict__ cond,
                                                                 int64_t N, const float *__restrict__ wb, float slope,
                                                                 float *__restrict__ score, float *__restrict__ part) {
@@ -341,7 +344,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ 
 }
 
 template <bool WGRAD, bool DX>
-__global__ __launch_bounds__(WAVES * 64) void k_critic_bwd_mfma(const float *__restrict__ x, const float *__restrict__ cond,
+__global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic_bwd_mfma(const float *__restrict__ x, const float *__restrict__ cond,
                                                                 int64_t N, const float *__restrict__ wb, float slope,
                                                                 const float *__restrict__ gscore, float gconst,
                                                                 float2 *__restrict__ gx, float *__restrict__ slab,
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_bwd_mfma(const float *__r
 // ---- gradient penalty, rows of L samples with L % 16 == 0 (or L == 1: every sample is its own row) -------
 // pass A: forward of x_hat, mask bits (one word per lane and tile), g per sample, sum |g|^2 per tile
 template <bool ROW1>
-__global__ __launch_bounds__(WAVES * 64) void k_gp_a_mfma(const float *__restrict__ real, const float *__restrict__ fake,
+__global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const float *__restrict__ real, const float *__restrict__ fake,
                                                           const float *__restrict__ cond, const float *__restrict__ alpha,
                                                           int64_t N, int64_t L, const float *__restrict__ wb, float slope,
                                                           float2 *__restrict__ gout, unsigned *__restrict__ maskw,
