@@ -123,6 +123,20 @@ def make_generator(ctx, qat):
     return gen.train()
 
 
+def pmc_traffic(ctx, qat):
+    """HBM bytes per launch of the fused Stage-1 kernel from the rocprofv3 counter passes recorded under
+    profiles/ (FETCH_SIZE doubled, the gfx950 correction, + WRITE_SIZE).  The counters cannot be read
+    from inside this process; the figure applies to the default shape only, otherwise null."""
+    path = os.path.join(ROOT, "profiles", "r1_stage1_pmc.json")
+    if qat or (ctx.rows, ctx.seq) != (16384, 1029) or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return int(json.load(f)["per_launch"]["hbm_bytes"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def run_stage1(ctx, args, qat, steps, warmup):
     from dpd_amd.training import Stage1Step
     gen = make_generator(ctx, qat)
@@ -138,7 +152,7 @@ def run_stage1(ctx, args, qat, steps, warmup):
     flop = 2.0 * (GEN_FWD_MAC + GEN_BWD_MAC) * ctx.n_local
     roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma: tap assembly + forward + MSE + backward, fp32 MFMA (+ slab reduce)",
             "achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
+            "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS, "traffic": pmc_traffic(ctx, qat),
             "flop_per_sample": 2 * (GEN_FWD_MAC + GEN_BWD_MAC), "kernel_ms": k * 1e3}
     loss = float(step.grads[1554].item())
     return dt, roof, {"loss": loss}
