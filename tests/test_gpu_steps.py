@@ -82,3 +82,26 @@ def test_stage1_many_steps_stay_finite():
         losses = torch.stack([step(iq, tgt).clone() for _ in range(24)]).flatten().cpu()
         assert torch.isfinite(losses).all()
         assert losses[-1] < losses[0]
+
+
+def test_training_harness_two_stage_and_resume(tmp_path):
+    """Two-stage schedule on synthetic rows: checkpoint dictionary and state-dict keys of the reference
+    (train.py:396-427), finite metrics, resume continues from the saved epoch."""
+    from dpd_amd.train import main
+    out = tmp_path / "ck"
+    args = ["--epochs", "2", "--stage1-epochs", "1", "--rows", "64", "--seq-len", "261", "--batch-size", "32",
+            "--config", "", "--output-dir", str(out), "--temp", "all", "--qat"]
+    m = main(args)
+    assert all(np.isfinite(m[k]) for k in ("val_evm_db", "val_nmse_db", "val_l1", "train_loss")) and m["stage"] == 2
+    ck = torch.load(out / "latest.pth", map_location="cpu", weights_only=False)
+    assert set(ck) == {"epoch", "generator_state_dict", "discriminator_state_dict", "g_optimizer_state_dict",
+                       "d_optimizer_state_dict", "best_evm", "config"}
+    assert ck["epoch"] == 1 and (out / "best.pth").exists()
+    g_keys = set(ck["generator_state_dict"])
+    assert {"fc1.weight", "fc3.bias", "input_quant.running_scale", "fc3_weight_quant.running_zero_point"} <= g_keys
+    d_keys = set(ck["discriminator_state_dict"])
+    assert {"features.0.linear.weight_orig", "features.4.linear.weight_u", "output.linear.weight_v", "output.linear.bias"} <= d_keys
+    m2 = main(["--epochs", "3", "--stage1-epochs", "1", "--rows", "64", "--seq-len", "261", "--batch-size", "32",
+               "--config", "", "--output-dir", str(out), "--resume", str(out / "latest.pth"), "--qat"])
+    assert np.isfinite(m2["val_evm_db"])
+    assert torch.load(out / "latest.pth", map_location="cpu", weights_only=False)["epoch"] == 2
