@@ -52,10 +52,18 @@ class Ctx:
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        # DPD_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- exercises the N > 1 code
+        # path on a one-GPU box (numbers from such a run mean nothing)
+        rehearsal = os.environ.get("DPD_BENCH_REHEARSAL") == "1"
+        if rehearsal:
+            self.local = 0
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
         if self.world > 1:
-            dist.init_process_group("nccl", device_id=self.dev)
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
         import dpd_amd  # noqa: F401
         from dpd_amd.data import ofdm_rows
         from dpd_amd.parallel import DataParallel
