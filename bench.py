@@ -207,8 +207,10 @@ def run_q88(ctx, args, steps, warmup):
     kt.close()
     k = kt.avg_seconds()
     mac = GEN_FWD_MAC * ctx.n_local
-    roof = {"bound": "valu-int", "kernel": "k_q88 (v_dot2_i32_i16)", "achieved": mac / k / 1e12, "peak": 157.3,
-            "unit": "TMAC/s", "frac": mac / k / 1e12 / 157.3, "traffic": None, "hbm_gbs": 8.0 * ctx.n_local / k / 1e9,
+    # v_dot2c_i32_i16 issues at 16 lanes per SIMD-cycle (half the fp32 FMA rate; scratch/ubench/dot2_rate.hip
+    # measures 36.4 T lane-instructions/s): 256 CU x 4 SIMD x 16 lanes x 2 MAC x 2.4 GHz = 78.6 TMAC/s
+    roof = {"bound": "valu-int", "kernel": "k_q88 (v_dot2c_i32_i16)", "achieved": mac / k / 1e12, "peak": 78.6,
+            "unit": "TMAC/s", "frac": mac / k / 1e12 / 78.6, "traffic": None, "hbm_gbs": 8.0 * ctx.n_local / k / 1e9,
             "acc64": eng.acc64, "kernel_ms": k * 1e3}
     return dt, roof, {"checksum": int(out[0].to(torch.int64).sum().item())}
 
