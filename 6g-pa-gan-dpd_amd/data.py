@@ -26,3 +26,37 @@ def ofdm_rows(batch: int, seq_len: int, seed: int, device, peak: float = 0.7) ->
     x = torch.cat([x[:, -5:], x], dim=1)
     x = x / x.abs().amax(dim=1, keepdim=True) * peak
     return torch.view_as_real(x).to(torch.float32).contiguous()
+
+
+def augment_rows(rows: torch.Tensor, strength: float = 0.1, seed: int = 0) -> torch.Tensor:
+    """Training-time augmentation of IQ rows [B, S, 2] on the device, one random draw per row and effect.
+
+    The effects and their ranges are those of the reference notebook's `augment_signal`
+    (training_colab.ipynb, data-loading cell): additive white noise at an SNR ~ N(40, 5) dB scaled by
+    `strength`; a phase offset of +-0.05 * strength rad; a gain of 1 +- 0.1 * strength; and a thermal
+    drift (one third of the rows each: cold = gain 1.05, phase -0.02 rad, compression 0.98; unchanged;
+    hot = 0.95, +0.03, 1.02) with AM-AM compression gain * (1 - 0.1 |x|^2 * compression).  The
+    reference draws one set of random numbers per call on the host; here every row gets its own draw
+    from a device generator (no host round trip), so parity is at the level of the distributions.
+    """
+    dev = rows.device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    B = rows.shape[0]
+    x = torch.view_as_complex(rows.contiguous())
+    power = (rows ** 2).mean(dim=(1, 2), keepdim=False)
+    snr_db = 40.0 + 5.0 * torch.randn(B, generator=g, device=dev)
+    noise_std = torch.sqrt(power / torch.pow(10.0, snr_db / 10.0)) * strength
+    noise = torch.randn(rows.shape, generator=g, device=dev) * noise_std.view(B, 1, 1)
+    x = x + torch.view_as_complex(noise)
+    phase = (torch.rand(B, generator=g, device=dev) - 0.5) * 0.1 * strength
+    gain = 1.0 + (torch.rand(B, generator=g, device=dev) - 0.5) * 0.2 * strength
+    x = x * torch.polar(gain, phase).view(B, 1)
+    # thermal drift: 0 = cold, 1 = unchanged, 2 = hot
+    state = torch.randint(0, 3, (B,), generator=g, device=dev)
+    t_gain = torch.tensor([1.05, 1.0, 0.95], device=dev)[state]
+    t_phase = torch.tensor([-0.02, 0.0, 0.03], device=dev)[state]
+    t_comp = torch.tensor([0.98, 0.0, 1.02], device=dev)[state]
+    mag2 = x.real ** 2 + x.imag ** 2
+    am = t_gain.view(B, 1) * (1.0 - 0.1 * mag2 * t_comp.view(B, 1))
+    x = x * am * torch.polar(torch.ones_like(t_phase), t_phase).view(B, 1)
+    return torch.view_as_real(x).to(torch.float32).contiguous()

@@ -180,6 +180,7 @@ def build_parser() -> argparse.ArgumentParser:
     p.add_argument("--seq-len", type=int, default=1029, help="row length L + 5 (L a power of two for the ACPR term)")
     p.add_argument("--rows", type=int, default=4096, help="synthetic training rows per rank")
     p.add_argument("--stage1-epochs", type=int, default=None, help="supervised epochs before the CWGAN-GP epochs")
+    p.add_argument("--augment", type=float, default=0.0, help="per-epoch augmentation strength of the input rows (0 = off)")
     return p
 
 
@@ -187,6 +188,7 @@ def main(argv=None) -> Dict[str, float]:
     args = build_parser().parse_args(argv)
     from . import _lib as L  # noqa: F401  (fails here, loudly, when the library is missing)
     from .models import WassersteinLoss  # noqa: F401
+    from .data import augment_rows
     from .parallel import DataParallel
     from .training import Stage1Step, Stage2Step
     from .utils.spectral_loss import create_spectral_loss
@@ -254,6 +256,8 @@ def main(argv=None) -> Dict[str, float]:
         for i in range(0, x_tr.shape[0] - batch + 1, batch):
             idx = perm[i:i + batch]
             xb, tb = x_tr[idx], t_tr[idx]
+            if args.augment > 0:
+                xb = augment_rows(xb, args.augment, seed=epoch * 100003 + i + rank)
             if epoch < s1_epochs:
                 logs.append(stage1(xb, tb).detach().reshape(1))
             else:

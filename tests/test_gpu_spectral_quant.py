@@ -189,3 +189,23 @@ def test_q88_export_from_generator():
     out = Q88Inference(w)(iq.to(DEV)).cpu().numpy()
     ref = oq.infer_rows(iq.numpy(), *(w[k].cpu().numpy() for k in ("w1", "b1", "w2", "b2", "w3", "b3", "lut")))
     assert np.array_equal(out, ref)
+
+
+def test_q88_long_prefix_bit_exact_vs_oracle():
+    """2^20 outputs (1024 rows of 1029) of the integer path against the numpy int64 oracle, bit for bit,
+    with trained-like weights exported from a seeded generator."""
+    from oracle import q88 as oq
+    from dpd_amd.models import TDNNGeneratorQAT
+    from dpd_amd.utils import Q88Inference, export_q88_weights
+    from gpu_util import ofdm_rows
+    torch.manual_seed(21)
+    gen = TDNNGeneratorQAT()
+    with torch.no_grad():
+        for fc in (gen.fc1, gen.fc2, gen.fc3):
+            fc.bias.uniform_(-0.2, 0.2)
+    w = export_q88_weights(gen.to(DEV))
+    iq = (ofdm_rows(1024, 1029, seed=8) * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
+    out = Q88Inference(w)(iq.to(DEV)).cpu().numpy()
+    wn = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in w.items()}
+    ref = oq.infer_rows(iq.numpy(), wn["w1"], wn["b1"], wn["w2"], wn["b2"], wn["w3"], wn["b3"], wn["lut"])
+    assert out.shape == ref.shape and np.array_equal(out, ref)

@@ -105,3 +105,22 @@ def test_training_harness_two_stage_and_resume(tmp_path):
                "--config", "", "--output-dir", str(out), "--resume", str(out / "latest.pth"), "--qat"])
     assert np.isfinite(m2["val_evm_db"])
     assert torch.load(out / "latest.pth", map_location="cpu", weights_only=False)["epoch"] == 2
+
+
+def test_augment_rows_distributions():
+    """Device-side augmentation: deterministic per seed, per-row draws, effects within the documented ranges."""
+    from dpd_amd.data import augment_rows, ofdm_rows
+    x = ofdm_rows(512, 261, seed=5, device=DEV)
+    a = augment_rows(x, strength=0.3, seed=1)
+    b = augment_rows(x, strength=0.3, seed=1)
+    c = augment_rows(x, strength=0.3, seed=2)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert a.shape == x.shape and bool(torch.isfinite(a).all())
+    # per-row gain: (1 +- 0.03) * thermal gain in {0.95, 1, 1.05} * compression (>= 1 - 0.1 * 0.49 * 1.02)
+    ratio = (a.pow(2).sum((1, 2)) / x.pow(2).sum((1, 2))).sqrt()
+    assert float(ratio.min()) > 0.95 * 0.97 * 0.94 and float(ratio.max()) < 1.05 * 1.03 * 1.001
+    assert float(ratio.std()) > 0.01                       # rows got different draws
+    # strength 0: only the thermal drift remains; a third of the rows are unchanged
+    z = augment_rows(x, strength=0.0, seed=3)
+    same = ((z - x).abs().amax((1, 2)) < 1e-6).float().mean()
+    assert 0.2 < float(same) < 0.47
