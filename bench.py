@@ -180,7 +180,9 @@ def run_stage2(ctx, args, steps, warmup):
     def fn():
         info.update(step(ctx.iq, ctx.target, cond))
     dt = ctx.timed(fn, steps, warmup)
-    # algorithmic work of one step (n_critic = 5): see DESIGN.md
+    # algorithmic work of one step (n_critic = 5): per critic update one generator forward, two critic
+    # forward+backward passes (real, fake) and the gradient penalty (forward, input gradient, double
+    # backward); per generator update forward, critic forward + input gradient, generator backward
     mac = 5 * (GEN_FWD_MAC + 2 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC) + (CRITIC_FWD_MAC + CRITIC_DX_MAC + CRITIC_BWD_MAC)) \
         + (GEN_FWD_MAC + CRITIC_FWD_MAC + CRITIC_DX_MAC + GEN_BWD_MAC)
     flop = 2.0 * mac * ctx.n_local
