@@ -421,7 +421,7 @@ __global__ __launch_bounds__(TPB) void k_gp_bwd(const float2 *__restrict__ g, co
 
 extern "C" int dpd_critic_forward(const float *x, const float *cond, int64_t N, const float *wb, float slope,
                                   float *score, float *score_sum, void *stream) {
-    DPD_REQUIRE(x && cond && wb && (score || score_sum), DPD_ERR_INVALID_ARG, "critic_forward: null pointer");
+    DPD_REQUIRE(((x && cond) || N == 0) && wb && (score || score_sum || N == 0), DPD_ERR_INVALID_ARG, "critic_forward: null pointer");
     DPD_REQUIRE(N >= 0, DPD_ERR_INVALID_ARG, "critic_forward: negative N");
     hipStream_t st = as_stream(stream);
     if (score_sum) DPD_HIP(hipMemsetAsync(score_sum, 0, sizeof(float), st));
@@ -436,7 +436,7 @@ extern "C" int dpd_critic_forward(const float *x, const float *cond, int64_t N, 
 extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope,
                                    const float *gscore, float gconst, float *grads, float *gx, float *score_sum,
                                    void *ws, size_t ws_bytes, void *stream) {
-    DPD_REQUIRE(x && cond && wb && (grads || gx), DPD_ERR_INVALID_ARG, "critic_backward: null pointer");
+    DPD_REQUIRE(((x && cond) || N == 0) && wb && (grads || gx || N == 0), DPD_ERR_INVALID_ARG, "critic_backward: null pointer");
     DPD_REQUIRE(!grads || (ws && ws_bytes >= dpd_workspace_bytes(0)), DPD_ERR_WORKSPACE, "critic_backward: workspace too small");
     hipStream_t st = as_stream(stream);
     if (score_sum) DPD_HIP(hipMemsetAsync(score_sum, 0, sizeof(float), st));
@@ -475,7 +475,7 @@ extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N,
 extern "C" int dpd_critic_gp(const float *real, const float *fake, const float *cond, const float *alpha, int64_t B,
                              int64_t L, const float *wb, float slope, float *gp, float *rownorm, float *grads,
                              void *ws, size_t ws_bytes, void *stream) {
-    DPD_REQUIRE(real && fake && cond && alpha && wb && gp && rownorm && grads, DPD_ERR_INVALID_ARG, "critic_gp: null pointer");
+    DPD_REQUIRE(((real && fake && cond && alpha && rownorm) || B == 0) && wb && gp && grads, DPD_ERR_INVALID_ARG, "critic_gp: null pointer");
     DPD_REQUIRE(B >= 0 && L >= 1, DPD_ERR_INVALID_ARG, "critic_gp: bad shape B=%lld L=%lld", (long long)B, (long long)L);
     const int64_t N = B * L;
     // workspace: slab | g [N,2] | masks [N] uint4 | rowc [B]

@@ -12,7 +12,7 @@ constexpr int64_t MFMA_MIN_SAMPLES = 4096;  // below this the VALU kernels win o
 
 int make_problem(GenProblem &p, const float *x, int64_t B, int64_t S, int pre, const float *wq, float slope, int qat,
                  float *absmax) {
-    DPD_REQUIRE(x && wq, DPD_ERR_INVALID_ARG, "generator: null input or weight pointer");
+    DPD_REQUIRE((x || B == 0) && wq, DPD_ERR_INVALID_ARG, "generator: null input or weight pointer");
     DPD_REQUIRE(B >= 0, DPD_ERR_INVALID_ARG, "generator: negative batch %lld", (long long)B);
     if (!pre) DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
     DPD_REQUIRE(!qat || absmax, DPD_ERR_INVALID_ARG, "generator: QAT needs the absmax buffer");
@@ -43,7 +43,7 @@ extern "C" size_t dpd_workspace_bytes(int64_t n_samples) {
 }
 
 extern "C" int dpd_tap_assembly(const float *iq, int64_t B, int64_t S, float *feat, void *stream) {
-    DPD_REQUIRE(iq && feat, DPD_ERR_INVALID_ARG, "tap_assembly: null pointer");
+    DPD_REQUIRE((iq && feat) || B == 0, DPD_ERR_INVALID_ARG, "tap_assembly: null pointer");
     DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
     if (B <= 0) return DPD_OK;
     return gen_launch_taps(iq, B, S, feat, as_stream(stream));
@@ -70,7 +70,7 @@ extern "C" int dpd_gen_absmax_pass(int stage, const float *x, int64_t B, int64_t
 }
 
 extern "C" int dpd_gen_quantize_output(float *out, int64_t n, const float *absmax, void *stream) {
-    DPD_REQUIRE(out && absmax && n >= 0, DPD_ERR_INVALID_ARG, "quantize_output: bad argument");
+    DPD_REQUIRE((out || n == 0) && absmax && n >= 0, DPD_ERR_INVALID_ARG, "quantize_output: bad argument");
     if (n == 0) return DPD_OK;
     return gen_launch_quantize_output(out, n, absmax, as_stream(stream));
 }
@@ -80,7 +80,7 @@ extern "C" int dpd_gen_forward(const float *x, int64_t B, int64_t S, int pre_ass
     GenProblem p;
     int rc = make_problem(p, x, B, S, pre_assembled, wq, slope, qat, absmax);
     if (rc) return rc;
-    DPD_REQUIRE(out, DPD_ERR_INVALID_ARG, "gen_forward: out is null");
+    DPD_REQUIRE(out || B == 0, DPD_ERR_INVALID_ARG, "gen_forward: out is null");
     hipStream_t st = as_stream(stream);
     if (!p.qat) return forward_dispatch(p, 4, out, impl, st);
     DPD_HIP(hipMemsetAsync(absmax, 0, 4 * sizeof(float), st));
@@ -120,7 +120,7 @@ extern "C" int dpd_gen_backward(const float *x, int64_t B, int64_t S, int pre_as
     GenProblem p;
     int rc = make_problem(p, x, B, S, pre_assembled, wq, slope, qat, const_cast<float *>(absmax));
     if (rc) return rc;
-    DPD_REQUIRE(grad_out, DPD_ERR_INVALID_ARG, "gen_backward: grad_out is null");
+    DPD_REQUIRE(grad_out || B == 0, DPD_ERR_INVALID_ARG, "gen_backward: grad_out is null");
     DPD_REQUIRE(!grad_feat || p.pre, DPD_ERR_INVALID_ARG, "gen_backward: grad_feat needs pre-assembled input");
     return backward_common(p, grad_out, nullptr, grads, nullptr, grad_feat, ws, ws_bytes, impl, as_stream(stream));
 }
@@ -131,7 +131,7 @@ extern "C" int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const flo
     GenProblem p;
     int rc = make_problem(p, iq, B, S, 0, wq, slope, qat, const_cast<float *>(absmax));
     if (rc) return rc;
-    DPD_REQUIRE(target && loss, DPD_ERR_INVALID_ARG, "gen_mse_step: null target or loss");
+    DPD_REQUIRE((target || B == 0) && loss, DPD_ERR_INVALID_ARG, "gen_mse_step: null target or loss");
     return backward_common(p, nullptr, target, grads, loss, nullptr, ws, ws_bytes, impl, as_stream(stream));
 }
 
@@ -142,7 +142,7 @@ extern "C" int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const flo
 extern "C" int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
                                   const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
                                   float *dpd_out, float *y, void *stream) {
-    DPD_REQUIRE(y && coef_re && coef_im, DPD_ERR_INVALID_ARG, "gen_pa_forward: null pointer");
+    DPD_REQUIRE((y || B == 0) && coef_re && coef_im, DPD_ERR_INVALID_ARG, "gen_pa_forward: null pointer");
     DPD_REQUIRE(K >= 1 && K <= 8 && M >= 1 && M <= 16, DPD_ERR_INVALID_ARG, "gen_pa_forward: K in 1..8, M in 1..16");
     GenProblem p;
     int rc = make_problem(p, iq, B, S, 0, wq, slope, qat, const_cast<float *>(absmax));

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_pa_bwd(const float2 *__restrict__ x, in
 }  // namespace
 
 static int pa_check(const float *x, int64_t B, int64_t S, const float *cre, const float *cim, int K, int M) {
-    DPD_REQUIRE(x && cre && cim, DPD_ERR_INVALID_ARG, "pa: null pointer");
+    DPD_REQUIRE((x || B == 0) && cre && cim, DPD_ERR_INVALID_ARG, "pa: null pointer");
     DPD_REQUIRE(K >= 1 && K <= MAXK && M >= 1 && M <= MAXM, DPD_ERR_INVALID_ARG, "pa: K=%d (1..8) or M=%d (1..16) unsupported", K, M);
     DPD_REQUIRE(B >= 0, DPD_ERR_INVALID_ARG, "pa: negative batch");
     DPD_REQUIRE(S >= M, DPD_ERR_SHAPE, "Sequence length %lld must be >= memory depth %d", (long long)S, M);
@@ -106,7 +106,7 @@ extern "C" int dpd_pa_forward(const float *x, int64_t B, int64_t S, const float 
                               int M, float *y, void *stream) {
     int rc = pa_check(x, B, S, coef_re, coef_im, K, M);
     if (rc) return rc;
-    DPD_REQUIRE(y, DPD_ERR_INVALID_ARG, "pa_forward: y is null");
+    DPD_REQUIRE(y || B == 0, DPD_ERR_INVALID_ARG, "pa_forward: y is null");
     const int64_t OL = S - M + 1, N = B * OL;
     if (N == 0) return DPD_OK;
     hipLaunchKernelGGL(k_pa_fwd<false>, dim3(grid_for(N, 256)), dim3(256), 0, as_stream(stream),
@@ -120,7 +120,7 @@ extern "C" int dpd_quant_pa_forward(float *x, int64_t B, int64_t S, const float 
                                     const float *coef_im, int K, int M, float *y, void *stream) {
     int rc = pa_check(x, B, S, coef_re, coef_im, K, M);
     if (rc) return rc;
-    DPD_REQUIRE(y && absmax3, DPD_ERR_INVALID_ARG, "quant_pa_forward: null pointer");
+    DPD_REQUIRE((y || B == 0) && absmax3, DPD_ERR_INVALID_ARG, "quant_pa_forward: null pointer");
     const int64_t OL = S - M + 1, N = B * OL;
     if (N == 0) return DPD_OK;
     hipLaunchKernelGGL(k_pa_fwd<true>, dim3(grid_for(N, 256)), dim3(256), 0, as_stream(stream),
@@ -134,7 +134,7 @@ extern "C" int dpd_pa_backward(const float *x, int64_t B, int64_t S, const float
                                int M, const float *gy, float *gx, void *stream) {
     int rc = pa_check(x, B, S, coef_re, coef_im, K, M);
     if (rc) return rc;
-    DPD_REQUIRE(gy && gx, DPD_ERR_INVALID_ARG, "pa_backward: null gradient pointer");
+    DPD_REQUIRE((gy && gx) || B == 0, DPD_ERR_INVALID_ARG, "pa_backward: null gradient pointer");
     const int64_t OL = S - M + 1, NX = B * S;
     if (NX == 0) return DPD_OK;
     hipLaunchKernelGGL(k_pa_bwd, dim3(grid_for(NX, 256)), dim3(256), 0, as_stream(stream),

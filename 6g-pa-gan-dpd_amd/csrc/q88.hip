@@ -178,7 +178,7 @@ __global__ __launch_bounds__(TPB) void k_q88(const int *__restrict__ iq, int64_t
 extern "C" int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int16_t *w1, const int16_t *b1,
                              const int16_t *w2, const int16_t *b2, const int16_t *w3, const int16_t *b3,
                              const int16_t *lut, int acc64, int16_t *out, void *stream) {
-    DPD_REQUIRE(iq && w1 && b1 && w2 && b2 && w3 && b3 && lut && out, DPD_ERR_INVALID_ARG, "q88_infer: null pointer");
+    DPD_REQUIRE(((iq && out) || B == 0) && w1 && b1 && w2 && b2 && w3 && b3 && lut, DPD_ERR_INVALID_ARG, "q88_infer: null pointer");
     DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
     auto aligned4 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 3) == 0; };
     DPD_REQUIRE(aligned4(iq) && aligned4(out) && aligned4(w1) && aligned4(b1) && aligned4(w2) && aligned4(b2) &&

@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void k_row_fq(const float *__restrict__ x, int
 
 extern "C" int dpd_quantize_fixed(const float *x, int64_t n, float scale, int bits, int is_signed, int dequant,
                                   float *out, void *stream) {
-    DPD_REQUIRE(x && out && n >= 0, DPD_ERR_INVALID_ARG, "quantize_fixed: bad argument");
+    DPD_REQUIRE(((x && out) || n == 0) && n >= 0, DPD_ERR_INVALID_ARG, "quantize_fixed: bad argument");
     DPD_REQUIRE(bits >= 2 && bits <= 24, DPD_ERR_INVALID_ARG, "quantize_fixed: bits %d not in 2..24", bits);
     if (n == 0) return DPD_OK;
     float qmin = is_signed ? -(float)(1 << (bits - 1)) : 0.f;
@@ -52,7 +52,7 @@ extern "C" int dpd_quantize_fixed(const float *x, int64_t n, float scale, int bi
 
 extern "C" int dpd_fake_quantize_dynamic(const float *x, int64_t rows, int64_t cols, int per_row, int n_bits,
                                          float *out, float *absmax_out, void *stream) {
-    DPD_REQUIRE(x && out && absmax_out, DPD_ERR_INVALID_ARG, "fake_quantize_dynamic: null pointer");
+    DPD_REQUIRE(((x && out) || rows == 0 || cols == 0) && absmax_out, DPD_ERR_INVALID_ARG, "fake_quantize_dynamic: null pointer");
     DPD_REQUIRE(rows >= 0 && cols >= 0 && rows <= 65535, DPD_ERR_INVALID_ARG, "fake_quantize_dynamic: bad shape");
     DPD_REQUIRE(n_bits >= 2 && n_bits <= 24, DPD_ERR_INVALID_ARG, "fake_quantize_dynamic: n_bits %d", n_bits);
     if (rows * cols == 0) return DPD_OK;

@@ -531,7 +531,7 @@ __global__ __launch_bounds__(256) void k_terms_bwd(const float *__restrict__ sta
 }  // namespace terms
 
 extern "C" int dpd_spectral_rowdb(const float *stats, int64_t B, int64_t L, float *rowdb, float *sums, void *stream) {
-    DPD_REQUIRE(stats && sums && B >= 0 && L >= 1, DPD_ERR_INVALID_ARG, "spectral_rowdb: bad argument");
+    DPD_REQUIRE((stats || B == 0) && sums && B >= 0 && L >= 1, DPD_ERR_INVALID_ARG, "spectral_rowdb: bad argument");
     hipLaunchKernelGGL(terms::k_rowdb, dim3(1), dim3(1024), 0, as_stream(stream), stats, B, (float)L, rowdb, sums);
     DPD_LAUNCH_CHECK();
     return DPD_OK;
@@ -547,7 +547,7 @@ extern "C" int dpd_spectral_loss_final(const float *sums, int64_t L, float w_l1,
 
 extern "C" int dpd_spectral_terms_backward(const float *stats, const float *coef, const float *gscale, int64_t B,
                                            int64_t L, float *gstats, void *stream) {
-    DPD_REQUIRE(stats && coef && gstats && B >= 0 && L >= 1, DPD_ERR_INVALID_ARG, "spectral_terms_backward: bad argument");
+    DPD_REQUIRE(((stats && gstats) || B == 0) && coef && B >= 0 && L >= 1, DPD_ERR_INVALID_ARG, "spectral_terms_backward: bad argument");
     if (B == 0) return DPD_OK;
     hipLaunchKernelGGL(terms::k_terms_bwd, dim3(grid_for(B, 256)), dim3(256), 0, as_stream(stream), stats, coef, gscale, B,
                        (float)L, gstats);
@@ -557,7 +557,7 @@ extern "C" int dpd_spectral_terms_backward(const float *stats, const float *coef
 
 extern "C" int dpd_spectral_stats(const float *pred, const float *target, int64_t B, int64_t L, const uint8_t *band,
                                   float *stats, void *stream) {
-    DPD_REQUIRE(pred && stats && (band || target), DPD_ERR_INVALID_ARG, "spectral_stats: null pointer");
+    DPD_REQUIRE(((pred && stats && (band || target)) || B <= 0), DPD_ERR_INVALID_ARG, "spectral_stats: null pointer");
     DPD_REQUIRE(L >= 1, DPD_ERR_INVALID_ARG, "spectral_stats: empty rows");
     int log2n = 0;
     DPD_REQUIRE(!band || check_len(L, &log2n), DPD_ERR_INVALID_ARG,
@@ -580,7 +580,7 @@ extern "C" int dpd_spectral_stats(const float *pred, const float *target, int64_
 
 extern "C" int dpd_spectral_backward(const float *pred, const float *target, int64_t B, int64_t L,
                                      const uint8_t *band, const float *gstats, float *dpred, void *stream) {
-    DPD_REQUIRE(pred && gstats && dpred && (band || target), DPD_ERR_INVALID_ARG, "spectral_backward: null pointer");
+    DPD_REQUIRE(((pred && gstats && dpred && (band || target)) || B <= 0), DPD_ERR_INVALID_ARG, "spectral_backward: null pointer");
     DPD_REQUIRE(L >= 1, DPD_ERR_INVALID_ARG, "spectral_backward: empty rows");
     int log2n = 0;
     DPD_REQUIRE(!band || check_len(L, &log2n), DPD_ERR_INVALID_ARG,

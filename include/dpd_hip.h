@@ -7,6 +7,9 @@
  * Calls are asynchronous on `stream`; no entry point synchronises the device or allocates
  * memory: scratch is caller-provided (`ws`, size from dpd_workspace_bytes()).
  *
+ * Empty batches (B, N or n equal to 0) are valid everywhere: the data pointers may then be NULL and
+ * outputs that are sums or gradients over the batch are zero-filled.
+ *
  * Return value: DPD_OK or a DPD_ERR_* code; dpd_last_error() gives the text for the calling
  * thread.  DPD_ERR_SHAPE marks the conditions on which the reference raises ValueError.
  *
