@@ -28,12 +28,17 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
 
 // kernel family: 0 = by size (MFMA from 1024 samples), 1 = VALU, 2 = MFMA
 static int g_critic_impl = 0;
+extern int g_gen_deterministic;
 static bool critic_use_mfma(int64_t N) { return g_critic_impl == 2 || (g_critic_impl == 0 && N >= 1024); }
 
 extern "C" int dpd_set_option(const char *name, int value) {
     DPD_REQUIRE(name, DPD_ERR_INVALID_ARG, "set_option: null name");
     if (__builtin_strcmp(name, "critic_impl") == 0 && value >= 0 && value <= 2) {
         g_critic_impl = value;
+        return DPD_OK;
+    }
+    if (__builtin_strcmp(name, "gen_deterministic") == 0 && (value == 0 || value == 1)) {
+        g_gen_deterministic = value;
         return DPD_OK;
     }
     dpd_set_error("set_option: unknown option %s or bad value %d", name, value);

@@ -614,9 +614,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // unit is started (one unit later): the compiler's own atomic sequence waits for the round trip at
     // once.  The compiler does not count this load, hence the explicit wait before the value is used;
     // by then the only other loads in flight are the next chunk's, which are needed at that point anyway.
+    unsigned static_next = blockIdx.x * WAVES + wave;     // queue == NULL: units in fixed round-robin order
     auto take = [&]() -> unsigned {
         unsigned v = 0;
-        if (lane == 0) {
+        if (queue == nullptr) {
+            v = static_next;
+            static_next += n_waves;
+        } else if (lane == 0) {
             const unsigned one = 1u;
             asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v) : "v"(queue), "v"(one) : "memory");
         }
@@ -769,6 +773,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 
 }  // namespace
 
+int g_gen_deterministic = 0;   // dpd_set_option("gen_deterministic", 0 / 1)
+
 static int mfma_grid(int64_t n_chunks, int per_cu = 2) {
     int64_t blocks = (n_chunks + WAVES - 1) / WAVES;
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;  // resident workgroups per CU
@@ -826,9 +832,10 @@ int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *t
                 "gen_backward: %lld chunks of 64 samples exceed the 32-bit chunk counter", (long long)n_chunks);
     const int gridn = mfma_grid(n_chunks, BWD_WAVES_PER_SIMD);
     *n_partials = gridn;
-    // chunk counter: one word behind the largest slab this call can write (the workspace is far larger)
-    unsigned *queue = reinterpret_cast<unsigned *>(slab + (size_t)1024 * G_SLAB);
-    DPD_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
+    // chunk counter: one word behind the largest slab this call can write (the workspace is far larger);
+    // none in deterministic mode (fixed assignment of chunks to waves: bitwise reproducible gradients)
+    unsigned *queue = g_gen_deterministic ? nullptr : reinterpret_cast<unsigned *>(slab + (size_t)1024 * G_SLAB);
+    if (queue) DPD_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
     const dim3 grid(gridn), block(WAVES * 64);
     const bool mse = grad_out == nullptr;
     const float mse_scale = mse ? (float)(2.0 / (2.0 * (double)p.N)) : 0.f;

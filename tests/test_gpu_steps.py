@@ -124,3 +124,30 @@ def test_augment_rows_distributions():
     z = augment_rows(x, strength=0.0, seed=3)
     same = ((z - x).abs().amax((1, 2)) < 1e-6).float().mean()
     assert 0.2 < float(same) < 0.47
+
+
+def test_generator_gradients_bitwise_reproducible_in_deterministic_mode():
+    """dpd_set_option("gen_deterministic", 1): two launches of the fused Stage-1 kernel give identical bits;
+    the default mode agrees with it to fp32 summation order."""
+    from dpd_amd import _lib as L
+    from dpd_amd.data import ofdm_rows
+    from dpd_amd.models import TDNNGeneratorQAT
+    from dpd_amd.training import Stage1Step
+    torch.manual_seed(3)
+    gen = TDNNGeneratorQAT().to(DEV)
+    gen.qat_enabled = False
+    iq = ofdm_rows(512, 1029, seed=2, device=DEV)
+    tgt = iq[:, 5:, :].contiguous()
+
+    def grads():
+        step = Stage1Step(gen, optimizer=torch.optim.SGD(gen.parameters(), lr=0.0))
+        step(iq, tgt)
+        return step.grads[:1554].clone()
+    L.call("dpd_set_option", b"gen_deterministic", 1)
+    try:
+        a, b = grads(), grads()
+    finally:
+        L.call("dpd_set_option", b"gen_deterministic", 0)
+    c = grads()
+    assert torch.equal(a, b)
+    close(c, a.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(a.abs().max()))
