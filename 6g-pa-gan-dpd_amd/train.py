@@ -119,7 +119,7 @@ def create_models(config: dict, qat: bool, device):
 
 def create_optimizers(gen, disc, config: dict):
     o = config["training"]["optimizer"]
-    kw = dict(betas=tuple(o.get("betas", [0.0, 0.9])), weight_decay=float(o.get("weight_decay", 1e-5)))
+    kw = dict(betas=tuple(o.get("betas", [0.0, 0.9])), weight_decay=float(o.get("weight_decay", 1e-5)), fused=True)
     return (torch.optim.Adam(gen.parameters(), lr=float(o.get("lr_generator", 1e-4)), **kw),
             torch.optim.Adam(disc.parameters(), lr=float(o.get("lr_discriminator", 1e-4)), **kw))
 
