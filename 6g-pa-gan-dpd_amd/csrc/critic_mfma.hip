@@ -369,6 +369,9 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
     }
     const f32x4 w4 = quad(lds, Q_W4, lane);
     float ssum = 0.f;
+#ifdef ABL_TIMING
+    unsigned long long tacc[6] = {0}, tlast = __builtin_readcyclecounter();
+#endif
     const int64_t ntiles = (N + 15) >> 4;
     // the tile's input (and upstream gradient) is loaded one tile ahead
     const int64_t stride = (int64_t)gridDim.x * WAVES;
@@ -388,7 +391,14 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
         in_next = fetch_in(tile + stride);
         gs_next = fetch_gs(tile + stride);
         Acts a;
+#ifdef ABL_TIMING
+#define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long now = __builtin_readcyclecounter(); tacc[k] += now - tlast; tlast = now; __builtin_amdgcn_sched_barrier(0); }
+        STAMP(0)
+#else
+#define STAMP(k)
+#endif
         tile_forward(a, lds, lane, in, slope);
+        STAMP(1)
         ssum += (valid && g == 0) ? a.score : 0.f;
         f32x4 m1[4], m2[2];
 #pragma unroll
@@ -398,6 +408,7 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
         const f32x4 gz3 = w4 * gs * mask4(a.h3, slope);
         f32x4 gz2[2], gz1[4];
         chain_down(lds, lane, gz3, m2, m1, gz2, gz1);
+        STAMP(2)
         if (DX) {
             float g0, g1;
             to_input(lds, lane, gz1, g0, g1);
@@ -412,10 +423,17 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
             // the input tile: column g of row j
             *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = in;
             outer_p1(ac, wbuf, ad, gz1, rc);
+            STAMP(3)
             outer_p2(ac, wbuf, ad, a.h1, gz2);
+            STAMP(4)
             outer_p3(ac, wbuf, ad, a.h2, gz3);
+            STAMP(5)
         }
     }
+#ifdef ABL_TIMING
+    if (WGRAD && lane == 0)
+        for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + k, tacc[k]);
+#endif
     if (!WGRAD) {
         if (score_sum) {   // no slab in this variant: one atomic per wave (order-dependent in the last bits)
             ssum = wave_sum(ssum);
