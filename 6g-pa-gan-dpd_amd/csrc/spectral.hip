@@ -319,22 +319,33 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_stats(const float2 *__r
     const Twiddles tw{s_t1, s_t2};
     unsigned bits[3];
     band_bits(bits, band, lane);
-    for (int64_t b = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; b < B; b += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
-        const float2 *p = pred + b * 1024;
+    // the next row's samples are loaded while the current row is transformed
+    const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
+    float2 nx[16], nt[16];
+    auto fetch = [&](int64_t b) {
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            nx[m] = b < B ? pred[b * 1024 + 64 * m + lane] : make_float2(0.f, 0.f);
+            nt[m] = (target && b < B) ? target[b * 1024 + 64 * m + lane] : make_float2(0.f, 0.f);
+        }
+    };
+    fetch((int64_t)blockIdx.x * ROWS_PER_BLOCK + wave);
+    for (int64_t b = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; b < B; b += stride) {
         cpx v[16];
         float s_abs = 0.f, s_err = 0.f, s_ref = 0.f;
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            const float2 x = p[64 * m + lane];
+            const float2 x = nx[m];
             v[m] = {x.x, x.y};
             if (target) {
-                const float2 t = target[b * 1024 + 64 * m + lane];
+                const float2 t = nt[m];
                 const float dx = x.x - t.x, dy = x.y - t.y;
                 s_abs += fabsf(dx) + fabsf(dy);
                 s_err += dx * dx + dy * dy;
                 s_ref += t.x * t.x + t.y * t.y;
             }
         }
+        fetch(b + stride);
         forward(v, tw, lds[wave], lane);
         float pm = 0.f, pl = 0.f, pu = 0.f;
 #pragma unroll
