@@ -630,7 +630,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
         return n_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)v);
     };
-    unsigned unit = blockIdx.x * WAVES + wave, next_raw = take(), in_unit = 0;
+    unsigned unit = blockIdx.x * WAVES + wave, next_raw = 0, in_unit = 0;
     unsigned chunk = unit * UNIT;
     ChunkIQ pre;
     float2 pre_tg = make_float2(0.f, 0.f);
@@ -653,10 +653,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         { __builtin_amdgcn_sched_barrier(0); unsigned long long now = __builtin_readcyclecounter(); tacc[16] += now - tlast; tlast = now; __builtin_amdgcn_sched_barrier(0); }
 #endif
         const int64_t t0_cur = t0;
+        // the counter is bumped right after the top-of-loop wait of a unit's second chunk, so the atomic
+        // has two chunks to return before anything waits on the memory counter again
+        if (in_unit == 1) next_raw = take();
         if (++in_unit == UNIT) {
             in_unit = 0;
             unit = uniform(next_raw);
-            next_raw = take();
         }
         chunk = unit * UNIT + in_unit;
         pre_tg = make_float2(0.f, 0.f);
