@@ -428,6 +428,186 @@ int grid_for_rows(int64_t B) {
 
 }  // namespace w1024
 
+
+// ------------------------------------------------------------------ L = 256: four rows per wave
+// 256 = 16 x 16.  A row occupies 16 lanes (lane group r = lane >> 4 of the wave, l = lane & 15), lane l
+// holds x[16 m + l]: 16-point DFT over m -> A[k1]; A[k1] *= W256^(l k1); one transposition through LDS
+// (lane k1' takes A_p[k1'], p = 0..15); 16-point DFT over p -> X[k1' + 16 k2] in register k2.  The
+// reverse order of the same stages is the second transform of the backward, as for 1,024 points.
+namespace w256 {
+
+using w1024::cpx;
+using w1024::cmul;
+using w1024::fft16;
+constexpr int WAVES = 4, ROWS_PER_WAVE = 4, ROWS_PER_BLOCK = WAVES * ROWS_PER_WAVE;
+constexpr int PITCH = 17;                         // complex words per k1 row (34 words: 16 lanes hit 16 bank pairs)
+constexpr int ROW_BUF = 16 * PITCH, BUF = ROWS_PER_WAVE * ROW_BUF;
+
+DEV void make_tw(float2 *t) {                     // t[k][l] = W256^(l k)
+    for (int i = threadIdx.x; i < 256; i += WAVES * 64) {
+        float s, c;
+        sincospif(-2.0f * (float)((i & 15) * (i >> 4)) / 256.0f, &s, &c);
+        t[i] = make_float2(c, s);
+    }
+    __syncthreads();
+}
+
+DEV void forward(cpx (&v)[16], const float2 *tw, float2 *buf, int l) {
+    fft16(v);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const float2 w = tw[16 * k + l];
+        v[k] = cmul(v[k], cpx{w.x, w.y});
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) buf[k * PITCH + l] = make_float2(v[k].x, v[k].y);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const float2 t = buf[l * PITCH + p];
+        v[p] = {t.x, t.y};
+    }
+    __builtin_amdgcn_wave_barrier();
+    fft16(v);
+}
+
+DEV void transposed(cpx (&v)[16], const float2 *tw, float2 *buf, int l) {
+    fft16(v);
+#pragma unroll
+    for (int p = 0; p < 16; ++p) buf[l * PITCH + p] = make_float2(v[p].x, v[p].y);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const float2 t = buf[k * PITCH + l];
+        v[k] = {t.x, t.y};
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const float2 w = tw[16 * k + l];
+        v[k] = cmul(v[k], cpx{w.x, w.y});
+    }
+    fft16(v);
+}
+
+DEV float sum16(float v) {     // over the 16 lanes of a row
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+DEV void band_bits(unsigned (&bits)[3], const uint8_t *__restrict__ band, int l) {
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+        bits[b] = 0u;
+#pragma unroll
+        for (int k2 = 0; k2 < 16; ++k2) bits[b] |= (band[b * 256 + l + 16 * k2] ? 1u : 0u) << k2;
+    }
+}
+
+__global__ __launch_bounds__(WAVES * 64) void k_stats(const float2 *__restrict__ pred, const float2 *__restrict__ target,
+                                                     int64_t B, const uint8_t *__restrict__ band, float *__restrict__ stats) {
+    __shared__ float2 lds[WAVES][BUF];
+    __shared__ float2 s_tw[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane >> 4, l = lane & 15;
+    make_tw(s_tw);
+    unsigned bits[3];
+    band_bits(bits, band, l);
+    float2 *buf = lds[wave] + r * ROW_BUF;
+    const int64_t n_groups = (B + ROWS_PER_WAVE - 1) / ROWS_PER_WAVE;
+    for (int64_t grp = (int64_t)blockIdx.x * WAVES + wave; grp < n_groups; grp += (int64_t)gridDim.x * WAVES) {
+        const int64_t b = grp * ROWS_PER_WAVE + r;
+        const bool live = b < B;
+        cpx v[16];
+        float s_abs = 0.f, s_err = 0.f, s_ref = 0.f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float2 x = live ? pred[b * 256 + 16 * m + l] : make_float2(0.f, 0.f);
+            v[m] = {x.x, x.y};
+            if (target && live) {
+                const float2 t = target[b * 256 + 16 * m + l];
+                const float dx = x.x - t.x, dy = x.y - t.y;
+                s_abs += fabsf(dx) + fabsf(dy);
+                s_err += dx * dx + dy * dy;
+                s_ref += t.x * t.x + t.y * t.y;
+            }
+        }
+        forward(v, s_tw, buf, l);
+        float pm = 0.f, pl = 0.f, pu = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pw = (v[i].x * v[i].x + v[i].y * v[i].y) * (1.0f / 256.0f);
+            pm += ((bits[0] >> i) & 1u) ? pw : 0.f;
+            pl += ((bits[1] >> i) & 1u) ? pw : 0.f;
+            pu += ((bits[2] >> i) & 1u) ? pw : 0.f;
+        }
+        s_abs = sum16(s_abs); s_err = sum16(s_err); s_ref = sum16(s_ref);
+        pm = sum16(pm); pl = sum16(pl); pu = sum16(pu);
+        if (l == 0 && live) {
+            float *o = stats + b * 8;
+            o[0] = s_abs; o[1] = s_err; o[2] = s_ref; o[3] = pm; o[4] = pl; o[5] = pu; o[6] = 0.f; o[7] = 0.f;
+        }
+    }
+}
+
+__global__ __launch_bounds__(WAVES * 64) void k_bwd(const float2 *__restrict__ pred, const float2 *__restrict__ target, int64_t B,
+                                                   const uint8_t *__restrict__ band, const float *__restrict__ gstats,
+                                                   float2 *__restrict__ dpred) {
+    __shared__ float2 lds[WAVES][BUF];
+    __shared__ float2 s_tw[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, r = lane >> 4, l = lane & 15;
+    make_tw(s_tw);
+    unsigned bits[3];
+    band_bits(bits, band, l);
+    float2 *buf = lds[wave] + r * ROW_BUF;
+    const int64_t n_groups = (B + ROWS_PER_WAVE - 1) / ROWS_PER_WAVE;
+    for (int64_t grp = (int64_t)blockIdx.x * WAVES + wave; grp < n_groups; grp += (int64_t)gridDim.x * WAVES) {
+        const int64_t b = grp * ROWS_PER_WAVE + r;
+        const bool live = b < B;
+        float g_abs = 0.f, g_err = 0.f, g_m = 0.f, g_l = 0.f, g_u = 0.f;
+        if (live) {
+            const float *gs = gstats + b * 8;
+            g_abs = gs[0]; g_err = gs[1]; g_m = gs[3]; g_l = gs[4]; g_u = gs[5];
+        }
+        cpx x[16], v[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            const float2 t = live ? pred[b * 256 + 16 * m + l] : make_float2(0.f, 0.f);
+            x[m] = {t.x, t.y};
+            v[m] = x[m];
+        }
+        // the four rows of a wave share the instruction stream: the transforms always run (zero weights give zero)
+        forward(v, s_tw, buf, l);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float w = (((bits[0] >> i) & 1u) ? g_m : 0.f) + (((bits[1] >> i) & 1u) ? g_l : 0.f) +
+                            (((bits[2] >> i) & 1u) ? g_u : 0.f);
+            v[i] = {w * v[i].x, -w * v[i].y};
+        }
+        transposed(v, s_tw, buf, l);
+        const float c2 = 2.0f / 256.0f;
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            float gx = c2 * v[m].x, gy = -c2 * v[m].y;
+            if (target && live) {
+                const float2 t = target[b * 256 + 16 * m + l];
+                const float dx = x[m].x - t.x, dy = x[m].y - t.y;
+                gx += g_abs * (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f)) + 2.f * g_err * dx;
+                gy += g_abs * (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f)) + 2.f * g_err * dy;
+            }
+            if (live) dpred[b * 256 + 16 * m + l] = make_float2(gx, gy);
+        }
+    }
+}
+
+int grid_for_rows(int64_t B) {
+    int64_t blocks = (B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    if (blocks > 256 * 4) blocks = 256 * 4;
+    return (int)(blocks < 1 ? 1 : blocks);
+}
+
+}  // namespace w256
+
 int check_len(int64_t L, int *log2n) {
     int l2 = 0;
     while ((1ll << l2) < L) ++l2;
@@ -581,6 +761,12 @@ extern "C" int dpd_spectral_stats(const float *pred, const float *target, int64_
         DPD_LAUNCH_CHECK();
         return DPD_OK;
     }
+    if (band && L == 256) {
+        hipLaunchKernelGGL(w256::k_stats, dim3(w256::grid_for_rows(B)), dim3(w256::WAVES * 64), 0, as_stream(stream),
+                           reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), B, band, stats);
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
     const size_t lds = band ? (size_t)(L + L / 2) * sizeof(float2) : 0;
     hipLaunchKernelGGL(k_spectral_stats, dim3((unsigned)B), dim3(TPB), lds, as_stream(stream),
                        reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), L, log2n,
@@ -601,6 +787,13 @@ extern "C" int dpd_spectral_backward(const float *pred, const float *target, int
         hipLaunchKernelGGL(w1024::k_bwd, dim3(w1024::grid_for_rows(B)), dim3(w1024::ROWS_PER_BLOCK * 64), 0,
                            as_stream(stream), reinterpret_cast<const float2 *>(pred),
                            reinterpret_cast<const float2 *>(target), B, band, gstats, reinterpret_cast<float2 *>(dpred));
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
+    if (band && L == 256) {
+        hipLaunchKernelGGL(w256::k_bwd, dim3(w256::grid_for_rows(B)), dim3(w256::WAVES * 64), 0, as_stream(stream),
+                           reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), B, band, gstats,
+                           reinterpret_cast<float2 *>(dpred));
         DPD_LAUNCH_CHECK();
         return DPD_OK;
     }

@@ -71,14 +71,15 @@ def test_band_masks_match_reference():
         assert np.array_equal(band_masks(n, 200e6, 100e6, 100e6, DEV).cpu().numpy(), g[f"mask{n}"])
 
 
-@pytest.mark.parametrize("n", [2, 8, 64, 512, 4096])
-def test_spectral_vs_oracle_lengths(n):
-    """Every supported FFT length, forward statistics and gradient, against the torch-CPU oracle."""
+@pytest.mark.parametrize("n,rows", [(2, 3), (8, 3), (64, 3), (512, 3), (4096, 3), (256, 1), (256, 7), (1024, 5), (1024, 9)])
+def test_spectral_vs_oracle_lengths(n, rows):
+    """Every supported FFT length (256 and 1,024 take the register-FFT kernels: four rows / one row per wave,
+    row counts that leave lane groups and waves idle), forward statistics and gradient, against the oracle."""
     from oracle import spectral as osp
     from dpd_amd.utils import SpectralLoss
     gen = torch.Generator().manual_seed(n)
-    tgt = torch.randn(3, n, 2, generator=gen) * 0.3
-    pred = (tgt + 0.05 * torch.randn(3, n, 2, generator=gen)).requires_grad_(True)
+    tgt = torch.randn(rows, n, 2, generator=gen) * 0.3
+    pred = (tgt + 0.05 * torch.randn(rows, n, 2, generator=gen)).requires_grad_(True)
     ref, comps = osp.spectral_loss(pred, tgt)
     (rg,) = torch.autograd.grad(ref, pred)
     p = pred.detach().to(DEV).requires_grad_(True)
