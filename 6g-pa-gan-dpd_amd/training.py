@@ -129,18 +129,18 @@ class Stage2Step:
         gen, disc, dp = self.gen, self.disc, self.dp
         info = {}
         d_params = list(disc.parameters())
-        fake = None
+        # The generator does not change until its own update at the end of the step, so one forward serves
+        # the whole step: its detached output feeds the critic updates, its autograd node the generator
+        # update.  The reference recomputes an identical forward n_critic + 1 times; only the
+        # running-scale bookkeeping of those forwards has to be repeated.
+        fake = gen(iq)
+        fake_d = fake.detach()
         for it in range(self.n_critic):
             self.d_opt.zero_grad(set_to_none=True)
-            if fake is None:
-                with torch.no_grad():
-                    fake = gen(iq)
-            elif hasattr(gen, "repeat_observation"):
-                # the generator does not change during the critic updates: the reference recomputes an
-                # identical forward each time; only its running-scale bookkeeping has to advance
+            if it > 0 and hasattr(gen, "repeat_observation"):
                 gen.repeat_observation()
             alpha = alphas[it] if alphas is not None else None
-            d_total, d_info = self._critic_loss(target, fake, cond, alpha)
+            d_total, d_info = self._critic_loss(target, fake_d, cond, alpha)
             d_total.backward()
             dp.sum_grads_(d_params)
             self.d_opt.step()
@@ -150,7 +150,8 @@ class Stage2Step:
         for p in d_params:
             p.requires_grad_(False)
         try:
-            fake = gen(iq)
+            if hasattr(gen, "repeat_observation"):
+                gen.repeat_observation()
             g_total, g_info = self._generator_loss(fake, target, cond)
             g_total.backward()
         finally:
