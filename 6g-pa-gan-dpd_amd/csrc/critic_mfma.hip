@@ -123,10 +123,9 @@ DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope
     a.score = s[0];
 }
 
-// back-propagation of an upstream vector through the three hidden layers:
+// back-propagation of an upstream vector through the three hidden layers, in two steps:
 //   top[r] (16 values on neurons 4g + r of layer 3, already masked) -> d2[2] (layer 2, masked) -> d1[4] (layer 1, masked)
-DEV void chain_down(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2], const f32x4 (&m1)[4], f32x4 (&d2)[2],
-                    f32x4 (&d1)[4]) {
+DEV void chain_top(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2]) {
     const f32x4 t0 = quad(img, Q_A3T, lane), t1 = quad(img, Q_A3T + 1, lane);
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -136,6 +135,8 @@ DEV void chain_down(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2],
     }
     d2[0] = e0 * m2[0];
     d2[1] = e1 * m2[1];
+}
+DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f32x4 (&m1)[4], f32x4 (&d1)[4]) {
     f32x4 f[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) f[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -151,6 +152,11 @@ DEV void chain_down(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2],
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) d1[t] = f[t] * m1[t];
+}
+DEV void chain_down(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2], const f32x4 (&m1)[4], f32x4 (&d2)[2],
+                    f32x4 (&d1)[4]) {
+    chain_top(img, lane, top, m2, d2);
+    chain_bottom(img, lane, d2, m1, d1);
 }
 
 // (W1[:, 0:2])^T d1 -> the two input-gradient components, in registers 0, 1 of every lane group
@@ -199,11 +205,17 @@ DEV void make_addr(Addr &ad, int j, int g) {
 #define ST4(base, off, v) (*reinterpret_cast<f32x4 *>((base) + (off)) = (v))
 #define LD1(base, off) (*reinterpret_cast<const float *>((base) + (off)))
 
+// Each outer-product phase is split in two: park_* stores this lane's rows of the factor tiles, run_* reads
+// them back transposed and issues the MFMAs.  The three phases share one buffer, so a phase is parked only
+// after the previous one has run; between a park and its run the caller places other MFMA work, which
+// covers the store -> read round trip through LDS (LDS operations of a wave execute in order).
 // p1 += left64^T (x) cst16 where the 16-column right tile lives in the wave's constant region
-DEV void outer_p1(Accum &ac, char *wb, const Addr &ad, const f32x4 (&left)[4], const int (&rc)[4]) {
+DEV void park_p1(char *wb, const Addr &ad, const f32x4 (&left)[4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) ST4(wb, ad.wl64 + 64 * t, left[t]);
     __builtin_amdgcn_wave_barrier();
+}
+DEV void run_p1(Accum &ac, char *wb, const Addr &ad, const int (&rc)[4]) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float r = LD1(wb, rc[q]);
@@ -212,12 +224,14 @@ DEV void outer_p1(Accum &ac, char *wb, const Addr &ad, const f32x4 (&left)[4], c
     }
     __builtin_amdgcn_wave_barrier();
 }
-DEV void outer_p2(Accum &ac, char *wb, const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
+DEV void park_p2(char *wb, const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) ST4(wb, ad.wl64 + 64 * t, left[t]);
     ST4(wb, ad.wr32, right[0]);
     ST4(wb, ad.wr32 + 64, right[1]);
     __builtin_amdgcn_wave_barrier();
+}
+DEV void run_p2(Accum &ac, char *wb, const Addr &ad) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float r0 = LD1(wb, ad.rr32[q]), r1 = LD1(wb, ad.rr32[q] + 64);
@@ -230,11 +244,13 @@ DEV void outer_p2(Accum &ac, char *wb, const Addr &ad, const f32x4 (&left)[4], c
     }
     __builtin_amdgcn_wave_barrier();
 }
-DEV void outer_p3(Accum &ac, char *wb, const Addr &ad, const f32x4 (&left)[2], f32x4 right) {
+DEV void park_p3(char *wb, const Addr &ad, const f32x4 (&left)[2], f32x4 right) {
     ST4(wb, ad.wl32, left[0]);
     ST4(wb, ad.wl32 + 64, left[1]);
     ST4(wb, ad.wr16, right);
     __builtin_amdgcn_wave_barrier();
+}
+DEV void run_p3(Accum &ac, char *wb, const Addr &ad) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const float r = LD1(wb, ad.rr16[q]);
@@ -407,8 +423,21 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
         m2[1] = mask4(a.h2[1], slope);
         const f32x4 gz3 = w4 * gs * mask4(a.h3, slope);
         f32x4 gz2[2], gz1[4];
-        chain_down(lds, lane, gz3, m2, m1, gz2, gz1);
+        // The outer-product phases are parked as soon as their factors exist and run after the next piece
+        // of the chain, whose MFMAs cover the LDS round trip: p3 (h2 x gz3) around the top of the chain,
+        // p2 (h1 x gz2) around its bottom; only p1 (gz1 x input) follows its own park directly.
+        if (WGRAD) park_p3(wbuf, ad, a.h2, gz3);
+        chain_top(lds, lane, gz3, m2, gz2);
+        if (WGRAD) {
+            run_p3(ac, wbuf, ad);
+            park_p2(wbuf, ad, a.h1, gz2);
+        }
+        chain_bottom(lds, lane, gz2, m1, gz1);
         STAMP(2)
+        if (WGRAD) {
+            run_p2(ac, wbuf, ad);
+            STAMP(4)
+        }
         if (DX) {
             float g0, g1;
             to_input(lds, lane, gz1, g0, g1);
@@ -422,12 +451,9 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
             db4 += gs;
             // the input tile: column g of row j
             *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = in;
-            outer_p1(ac, wbuf, ad, gz1, rc);
+            park_p1(wbuf, ad, gz1);
+            run_p1(ac, wbuf, ad, rc);
             STAMP(3)
-            outer_p2(ac, wbuf, ad, a.h1, gz2);
-            STAMP(4)
-            outer_p3(ac, wbuf, ad, a.h2, gz3);
-            STAMP(5)
         }
     }
 #ifdef ABL_TIMING
@@ -619,7 +645,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
         for (int r = 0; r < 4; ++r) m3[r] = ((bits >> (24 + r)) & 1u) ? 1.f : slope;
         const f32x4 v3 = w4 * m3;
         f32x4 v2[2], v1[4];
-        chain_down(lds, lane, v3, m2, m1, v2, v1);
         // du1 = (W1[:, 0:2] gh) * D1 : k = input column on the lane groups (groups 2, 3 carry zeros)
         const float ghb = g == 0 ? gh0 : (g == 1 ? gh1 : 0.f);
         f32x4 du1[4];
@@ -637,6 +662,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
             }
         }
         f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
+        // every outer-product phase is parked as soon as its factors exist and run after the next block of
+        // chain MFMAs (which covers the LDS round trip): p3 = du2 x v3, p2 = du1 x v2, p1 = v1 x gh
+        park_p3(wbuf, ad, du2, v3);
         // dv3 = W3 du2 ; dW4 += dv3 * D3
         f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
         const f32x4 w30 = quad(lds, Q_A3, lane), w31 = quad(lds, Q_A3 + 1, lane);
@@ -646,11 +674,15 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
             y1 = mfma4(w31[r], du2[1][r], y1);
         }
         dw4 += (y0 + y1) * m3;
+        run_p3(ac, wbuf, ad);
+        chain_top(lds, lane, v3, m2, v2);
+        park_p2(wbuf, ad, du1, v2);
+        chain_bottom(lds, lane, v2, m1, v1);
+        run_p2(ac, wbuf, ad);
         // gh tile: column g (< 2) of row j
         if (g < 2) *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = ghb;
-        outer_p1(ac, wbuf, ad, v1, rc);
-        outer_p2(ac, wbuf, ad, du1, v2);
-        outer_p3(ac, wbuf, ad, du2, v3);
+        park_p1(wbuf, ad, v1);
+        run_p1(ac, wbuf, ad, rc);
     }
     __syncthreads();
     float *row = lds + wave * C_SLAB;
