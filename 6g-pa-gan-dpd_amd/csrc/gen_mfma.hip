@@ -29,7 +29,7 @@ constexpr int WAVES = 4;
 #define BWD_WAVES_PER_SIMD 2        // measured: 2 resident waves per SIMD (<= 256 registers, no spills) beat 3 with spills
 #endif
 #ifndef FWD_WAVES_PER_SIMD
-#define FWD_WAVES_PER_SIMD 4        // forward only: <= 128 registers
+#define FWD_WAVES_PER_SIMD 5        // forward only: <= 102 registers (measured: 3..6 within 4 %, 5 best)
 #endif
 constexpr int CHUNK = 64;           // samples per wave iteration
 constexpr int SER_STRIDE = 71;      // words between series (71 = 7 mod 32: bank-disjoint operand reads)
