@@ -149,6 +149,33 @@ DEV float tanh_f32(float x) {
     return ax < 0.1f ? small : big;
 }
 
+// FC3 of a tile pair on the VALU: 2 outputs x 16 neurons fill an eighth of a 16x16x4 MFMA tile, while
+// the per-lane partial sums (this lane group's four h2 neurons) cost 16 FMAs for both tiles and the
+// sum over the four lane groups takes three row swaps.  Lane (g, j) ends up with z3[g & 1] of sample j
+// of tile g >> 1.  w3[k][r] = W3[k][4g + r]; b3k = b3[g & 1].
+DEV float fc3_pair(const float (&w3)[2][4], float b3k, const f32x4 &hA, const f32x4 &hB) {
+    float pa0 = w3[0][0] * hA[0], pa1 = w3[1][0] * hA[0], pb0 = w3[0][0] * hB[0], pb1 = w3[1][0] * hB[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) {
+        pa0 = __builtin_fmaf(w3[0][r], hA[r], pa0);
+        pa1 = __builtin_fmaf(w3[1][r], hA[r], pa1);
+        pb0 = __builtin_fmaf(w3[0][r], hB[r], pb0);
+        pb1 = __builtin_fmaf(w3[1][r], hB[r], pb1);
+    }
+    // halves: lanes 0..31 collect tile A (rows g and g + 2), lanes 32..63 tile B
+    const auto h0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa0), __builtin_bit_cast(unsigned, pb0), false, false);
+    const auto h1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa1), __builtin_bit_cast(unsigned, pb1), false, false);
+    unsigned x0 = h0[0], y0 = h0[1], x1 = h1[0], y1 = h1[1];
+    asm volatile("" : "+v"(x0), "+v"(y0), "+v"(x1), "+v"(y1));   // keeps both results of a swap apart
+    const float s0 = __builtin_bit_cast(float, x0) + __builtin_bit_cast(float, y0);
+    const float s1 = __builtin_bit_cast(float, x1) + __builtin_bit_cast(float, y1);
+    // rows: even rows collect output 0, odd rows output 1
+    const auto q = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s0), __builtin_bit_cast(unsigned, s1), false, false);
+    unsigned u = q[0], v = q[1];
+    asm volatile("" : "+v"(u), "+v"(v));
+    return (__builtin_bit_cast(float, u) + __builtin_bit_cast(float, v)) + b3k;
+}
+
 // Forward only.  DEPTH limits how far a tile runs (1: through act1, 2: through act2, >= 3: to the output);
 // the QAT instances with DEPTH 1..3 are the abs-max passes of the three activation quantisers.  Two tiles
 // (A, B) of the chunk run half a stage apart in one instruction stream (the VALU stage of one in the
@@ -392,7 +419,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) A2T[t][r] = wq[G_W2 + (4 * g + r) * 32 + 16 * t + j];
-    const float A3T = g < 2 ? wq[G_W3 + g * 16 + j] : 0.f;   // W3^T as an A operand: k = output index = lane group
+    float w3v[2][4];  // W3[k][4g + r]: FC3 and its input gradient run on the VALU
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w3v[k][r] = wq[G_W3 + k * 16 + 4 * g + r];
+    const float b3k = wq[G_B3 + (g & 1)];
     int boff[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
@@ -438,14 +470,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     float2 *const tg_lds = reinterpret_cast<float2 *>(ser + TG_W);
     const float *const tg_f = ser + TG_W;
 
-    // One tile's life is a strict alternation of MFMA stages (S1 FC1, S2 FC2, S3 FC3, S4 gh2, S5 gh1,
-    // S6 weight-gradient outer products) and VALU/LDS stages (V1..V5) that each need the previous MFMA
-    // result.  Two tiles (A, B) of the chunk run half a stage apart in one instruction stream, so the
-    // VALU stage of one tile sits in the shadow of the other tile's MFMAs:
-    //   S1A | S1B+V1A | S2A+V1B | S2B+V2A | S3A+V2B | S3B+V3A | S4A+V3B | S4B+V4A | S5A+V4B | S5B+V5A | S6A+V5B | S6B
+    // One tile's life is an alternation of MFMA stages (S1 FC1, S2 FC2, S5 gh1, S6 weight-gradient outer
+    // products) and VALU/LDS stages (V1, V2, the output stage of the pair with FC3 and its gradients, V4,
+    // V5) that each need the previous result.  Two tiles (A, B) of the chunk run half a stage apart in
+    // one instruction stream, so the VALU stage of one tile sits in the shadow of the other's MFMAs:
+    //   S1A | S1B+V1A | S2A+V1B | S2B+V2A | V2B+V3(A,B)+V4A | S5A+V4B | S5B+V5A | S6A+V5B | S6B
     struct Tile {
-        f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, z3, gz2, e0, e1;
-        float gsel;
+        f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, gz2, e0, e1;
     };
     // FC1 operands are fetched from LDS one stage before the MFMAs that use them
     auto F1 = [&](float (&b)[8], int c) {
@@ -495,18 +526,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #pragma unroll
         for (int r = 0; r < 4; ++r) t.h2[r] = QAT ? fq16(t.c0[r], s2) : t.c0[r];
     };
-    auto S3 = [&](Tile &t) {
-        t.z3 = w.bias3;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t.z3 = mfma4(w.A3[r], t.h2[r], t.z3);
-    };
     // Output stage of a tile pair: 32 samples x 2 outputs = one (sample, output) per lane.  Lane (g, j)
-    // takes output g & 1 of sample j of tile g >> 1 (every lane group holds z3 of its own sample j), so
-    // tanh, loss and gz3 are evaluated once each; gz3 then goes to all lane groups with three row swaps.
+    // takes output g & 1 of sample j of tile g >> 1, so tanh, loss and gz3 are evaluated once each; gz3
+    // then goes to all lane groups with three row swaps, where dW3 and gh2 = W3^T gz3 (two FMAs per
+    // neuron) follow on the VALU.
     const int tg_off = 2 * (16 * (g >> 1) + j) + (g & 1);
     auto V3P = [&](Tile &A, Tile &B, int p, int64_t t0_cur) {
-        const float zA = odd ? A.z3[1] : A.z3[0], zB = odd ? B.z3[1] : B.z3[0];
-        const float y = tanh_f32(g >= 2 ? zB : zA);
+        const float y = tanh_f32(fc3_pair(w3v, b3k, A.h2, B.h2));
         const bool valid = (t0_cur + 32 * p + 16 * (g >> 1) + j) < L;
         const float v = tg_f[tg_off + 64 * p];
         float gup;
@@ -538,14 +564,15 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             dW3[0][r4] = __builtin_fmaf(b0, B.h2[r4], dW3[0][r4]);
             dW3[1][r4] = __builtin_fmaf(b1, B.h2[r4], dW3[1][r4]);
         }
-        A.gsel = odd ? a1 : a0;
-        B.gsel = odd ? b1 : b0;
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+            A.gz2[r4] = __builtin_fmaf(w3v[1][r4], a1, w3v[0][r4] * a0) * A.m2[r4];
+            B.gz2[r4] = __builtin_fmaf(w3v[1][r4], b1, w3v[0][r4] * b0) * B.m2[r4];
+        }
+        db2 += A.gz2;
+        db2 += B.gz2;
     };
-    // gh2^T = W3^T gz3^T: one MFMA with k = output index on the lane groups (groups 2, 3 multiply zeros)
-    auto S4 = [&](Tile &t) { t.gz2 = mfma4(A3T, t.gsel, f32x4{0.f, 0.f, 0.f, 0.f}); };
     auto V4 = [&](Tile &t, int buf) {
-        t.gz2 *= t.m2;
-        db2 += t.gz2;
         *reinterpret_cast<f32x4 *>(ser_b + 4 * (GZ_W + TILE_W * buf) + wr32 + 128) = t.gz2;
     };
     auto S5 = [&](Tile &t) {   // gh1^T = W2^T gz2^T  (two row tiles of 16 h1-neurons)
@@ -694,18 +721,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             S2(B);
             V2(A);
             PHASE();
-            S3(A);
             V2(B);
-            PHASE();
-            S3(B);
-            PHASE();
             V3P(A, B, p, t0_cur);
-            PHASE();
-            S4(A);
-            S4(B);
             V4(A, 0);
             PHASE();
-
             S5(A);
             V4(B, 1);
             PHASE();
