@@ -113,10 +113,7 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
 struct FwdWeights {
     float A1[2][8];   // W1 tile t, step s: lane (i, g) holds W1[16t + i][slot 4s + g]
     float A2[2][4];   // W2[i][16t + 4g + r]
-    float A3[4];      // W3 with its two rows repeated at rows 4q, 4q+1 of a 16-row tile: every lane
-                      // group then finds z3_0, z3_1 in registers 0, 1 of the result (no cross-lane sum)
     f32x4 bias2;      // b2[4g + r]
-    f32x4 bias3;      // (b3_0, b3_1, 0, 0)
 };
 
 DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, int g) {
@@ -132,10 +129,7 @@ DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, in
 #pragma unroll
         for (int r = 0; r < 4; ++r) w.A2[t][r] = wq[G_W2 + j * 32 + 16 * t + 4 * g + r];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) w.A3[r] = (j & 3) < 2 ? wq[G_W3 + (j & 3) * 16 + 4 * g + r] : 0.f;
-#pragma unroll
     for (int r = 0; r < 4; ++r) w.bias2[r] = wq[G_B2 + 4 * g + r];
-    w.bias3 = f32x4{wq[G_B3], wq[G_B3 + 1], 0.f, 0.f};
 }
 
 // tanh to fp32 rounding level: odd series below 0.1 (next term 62/2835 x^9 < 2e-11), above it
@@ -221,6 +215,12 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         int slot = 4 * s + g;
         boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
+    float w3v[2][4];  // W3[k][4g + r]: FC3 runs on the VALU
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w3v[k][r] = wq[G_W3 + k * 16 + 4 * g + r];
+    const float b3k = wq[G_B3 + (g & 1)];
     QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
     if (QAT) {
         s0 = qs_of(absmax[0]);
@@ -233,7 +233,7 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
     const bool odd = (g & 1) != 0;
 
     struct Tile {
-        f32x4 a0, a1, ha, hb, c0, c1, h2, z3;
+        f32x4 a0, a1, ha, hb, c0, c1, h2;
     };
     auto S1 = [&](Tile &t, int c) {
         t.a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
@@ -271,11 +271,6 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
             t.h2[r] = (QAT && DEPTH >= 3) ? fq16(x, s2) : x;
             if (QAT && DEPTH == 2) amax = fmaxf(amax, valid ? fabsf(x) : 0.f);
         }
-    };
-    auto S3 = [&](Tile &t) {
-        t.z3 = w.bias3;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t.z3 = mfma4(w.A3[r], t.h2[r], t.z3);
     };
 #define PHASE() __builtin_amdgcn_sched_barrier(0)
 
@@ -324,14 +319,9 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                 V2(A, vA);
                 PHASE();
                 if (DEPTH >= 3) {
-                    S3(A);
                     V2(B, vB);
-                    PHASE();
-                    S3(B);
-                    PHASE();
-                    // lane (g, j): output g & 1 of sample j of tile g >> 1 (every lane group holds z3 of its sample j)
-                    const float zA = odd ? A.z3[1] : A.z3[0], zB = odd ? B.z3[1] : B.z3[0];
-                    float y = tanh_f32(g >= 2 ? zB : zA);
+                    // lane (g, j): output g & 1 of sample j of tile g >> 1
+                    float y = tanh_f32(fc3_pair(w3v, b3k, A.h2, B.h2));
                     const int64_t t = t0_cur + 32 * p + 16 * (g >> 1) + j;
                     if (QAT && !PA) amax = fmaxf(amax, t < L ? fabsf(y) : 0.f);
                     if (QAT && PA) y = fq16(y, s3);
