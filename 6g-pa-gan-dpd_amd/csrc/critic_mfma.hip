@@ -19,23 +19,24 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+// sixteen independent 4x4 outer products: lane 4b + i of `a` times lane 4b + j of `b` -> register i of lane 4b + j
+DEV f32x4 mfma_blocks(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
 constexpr int WAVES = 4;
 // operand image: quads of four consecutive k-steps per lane
 constexpr int Q_A1 = 0;     // [t]            e = t : W1[16t + i][g]
 constexpr int Q_A2 = 1;     // [u][t]         e = r : W2[16u + i][16t + 4g + r]
 constexpr int Q_A3 = 9;     // [u]            e = r : W3[i][16u + 4g + r]
-constexpr int Q_A4 = 11;    //                e = r : (i & 3) == 0 ? W4[4g + r] : 0
-constexpr int Q_A3T = 12;   // [u]            e = r : W3[4g + r][16u + i]
-constexpr int Q_A2T = 14;   // [t][u]         e = r : W2[16u + 4g + r][16t + i]
-constexpr int Q_A1T = 22;   // [t]            e = r : (i & 3) < 2 ? W1[16t + 4g + r][i & 3] : 0
-constexpr int Q_B1 = 26;    // [t]            e = r : b1[16t + 4g + r]
-constexpr int Q_B2 = 30;    // [u]            e = r : b2[16u + 4g + r]
-constexpr int Q_B3 = 32;    //                e = r : b3[4g + r]
-constexpr int Q_B4 = 33;    //                e = 0 : b4, else 0
-constexpr int Q_W4 = 34;    //                e = r : W4[4g + r]
-constexpr int NQUAD = 35;
-constexpr int IMG_WORDS = NQUAD * 64 * 4;          // 8960
+constexpr int Q_A3T = 11;   // [u]            e = r : W3[4g + r][16u + i]
+constexpr int Q_A2T = 13;   // [t][u]         e = r : W2[16u + 4g + r][16t + i]
+constexpr int Q_W1C = 21;   // [c][t]         e = r : W1[16t + 4g + r][c], c = 0, 1 (the two x columns; VALU operand)
+constexpr int Q_B1 = 29;    // [t]            e = r : b1[16t + 4g + r]
+constexpr int Q_B2 = 33;    // [u]            e = r : b2[16u + 4g + r]
+constexpr int Q_B3 = 35;    //                e = r : b3[4g + r]
+constexpr int Q_B4 = 36;    //                e = 0 : b4, else 0
+constexpr int Q_W4 = 37;    //                e = r : W4[4g + r] (VALU operand)
+constexpr int NQUAD = 38;
+constexpr int IMG_WORDS = NQUAD * 64 * 4;          // 9728
 // per-wave transposition buffer
 constexpr int P64 = 80, P32 = 48, P16 = 16;        // row pitches: 16 mod 32 -> rows s, s+1 hit different bank halves
 constexpr int LEFT_W = 0, RIGHT_W = 16 * P64, CONST_W = RIGHT_W + 16 * P32;
@@ -54,11 +55,10 @@ DEV void build_image(float *img, const float *__restrict__ wb) {
             float x = 0.f;
             if (q == Q_A1) x = wb[C_W1 + (16 * e + i) * 4 + g];
             else if (q < Q_A3) { int u = (q - Q_A2) >> 2, t = (q - Q_A2) & 3; x = wb[C_W2 + (16 * u + i) * 64 + 16 * t + 4 * g + e]; }
-            else if (q < Q_A4) { int u = q - Q_A3; x = wb[C_W3 + i * 32 + 16 * u + 4 * g + e]; }
-            else if (q == Q_A4) x = (i & 3) == 0 ? wb[C_W4 + 4 * g + e] : 0.f;
+            else if (q < Q_A3T) { int u = q - Q_A3; x = wb[C_W3 + i * 32 + 16 * u + 4 * g + e]; }
             else if (q < Q_A2T) { int u = q - Q_A3T; x = wb[C_W3 + (4 * g + e) * 32 + 16 * u + i]; }
-            else if (q < Q_A1T) { int t = (q - Q_A2T) >> 1, u = (q - Q_A2T) & 1; x = wb[C_W2 + (16 * u + 4 * g + e) * 64 + 16 * t + i]; }
-            else if (q < Q_B1) { int t = q - Q_A1T; x = (i & 3) < 2 ? wb[C_W1 + (16 * t + 4 * g + e) * 4 + (i & 3)] : 0.f; }
+            else if (q < Q_W1C) { int t = (q - Q_A2T) >> 1, u = (q - Q_A2T) & 1; x = wb[C_W2 + (16 * u + 4 * g + e) * 64 + 16 * t + i]; }
+            else if (q < Q_B1) { int c = (q - Q_W1C) >> 2, t = (q - Q_W1C) & 3; x = wb[C_W1 + (16 * t + 4 * g + e) * 4 + c]; }
             else if (q < Q_B2) { int t = q - Q_B1; x = wb[C_B1 + 16 * t + 4 * g + e]; }
             else if (q < Q_B3) { int u = q - Q_B2; x = wb[C_B2 + 16 * u + 4 * g + e]; }
             else if (q == Q_B3) x = wb[C_B3 + 4 * g + e];
@@ -91,7 +91,24 @@ DEV f32x4 mask4(f32x4 h, float slope) {
     return m;
 }
 
-// forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group)
+// sum of a per-lane value over the four lane groups (same j), left in every lane: two row swaps.  The
+// swap results pass through an empty asm: this compiler otherwise folds the second result of a swap
+// into the first once they are reinterpreted as floats.
+DEV float sum_over_groups(float v) {
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(b, b, false, false);       // rows (0,0,2,2), (1,1,3,3)
+    unsigned u0 = r[0], u1 = r[1];
+    asm volatile("" : "+v"(u0), "+v"(u1));
+    const float s = __builtin_bit_cast(float, u0) + __builtin_bit_cast(float, u1);
+    const unsigned c = __builtin_bit_cast(unsigned, s);
+    const auto q = __builtin_amdgcn_permlane32_swap(c, c, false, false);       // lower half, upper half
+    unsigned w0 = q[0], w1 = q[1];
+    asm volatile("" : "+v"(w0), "+v"(w1));
+    return __builtin_bit_cast(float, w0) + __builtin_bit_cast(float, w1);
+}
+
+// forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).  The last
+// layer (16 -> 1) runs on the VALU: four FMAs per lane and a sum over the lane groups.
 DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope) {
     const f32x4 a1 = quad(img, Q_A1, lane);
 #pragma unroll
@@ -116,11 +133,11 @@ DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope
         y1 = mfma4(w31[r], a.h2[1][r], y1);
     }
     a.h3 = lrelu4(y0 + y1, slope);
-    f32x4 s = quad(img, Q_B4, lane);
-    const f32x4 w4 = quad(img, Q_A4, lane);
+    const f32x4 w4 = quad(img, Q_W4, lane);
+    float s = w4[0] * a.h3[0];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) s = mfma4(w4[r], a.h3[r], s);
-    a.score = s[0];
+    for (int r = 1; r < 4; ++r) s = __builtin_fmaf(w4[r], a.h3[r], s);
+    a.score = sum_over_groups(s) + img[(Q_B4 * 64 + lane) * 4];
 }
 
 // back-propagation of an upstream vector through the three hidden layers, in two steps:
@@ -159,25 +176,40 @@ DEV void chain_down(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2],
     chain_bottom(img, lane, d2, m1, d1);
 }
 
-// (W1[:, 0:2])^T d1 -> the two input-gradient components, in registers 0, 1 of every lane group
+// (W1[:, 0:2])^T d1 -> the two input-gradient components, in every lane of sample j.  Two of sixteen
+// rows of an MFMA tile would be used, so this runs on the VALU: 32 FMAs per lane over its 16 neurons,
+// then the sum over the four lane groups for both components with three row swaps.
 DEV void to_input(const float *img, int lane, const f32x4 (&d1)[4], float &g0, float &g1) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
+    float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; t += 2) {
-        const f32x4 w0 = quad(img, Q_A1T + t, lane), w1 = quad(img, Q_A1T + t + 1, lane);
+    for (int t = 0; t < 4; ++t) {
+        const f32x4 w0 = quad(img, Q_W1C + t, lane), w1 = quad(img, Q_W1C + 4 + t, lane);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            a = mfma4(w0[r], d1[t][r], a);
-            b = mfma4(w1[r], d1[t + 1][r], b);
+            p0 = __builtin_fmaf(w0[r], d1[t][r], p0);
+            p1 = __builtin_fmaf(w1[r], d1[t][r], p1);
         }
     }
-    g0 = a[0] + b[0];
-    g1 = a[1] + b[1];
+    // halves: lanes 0..31 collect component 0 (rows g and g + 2), lanes 32..63 component 1
+    const auto h = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), false, false);
+    unsigned x = h[0], y = h[1];
+    asm volatile("" : "+v"(x), "+v"(y));
+    const unsigned s = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, x) + __builtin_bit_cast(float, y));
+    const auto r = __builtin_amdgcn_permlane16_swap(s, s, false, false);
+    unsigned u = r[0], v = r[1];
+    asm volatile("" : "+v"(u), "+v"(v));
+    const unsigned tot = __builtin_bit_cast(unsigned, __builtin_bit_cast(float, u) + __builtin_bit_cast(float, v));
+    const auto q = __builtin_amdgcn_permlane32_swap(tot, tot, false, false);   // component 0 | component 1 everywhere
+    unsigned a = q[0], b = q[1];
+    asm volatile("" : "+v"(a), "+v"(b));
+    g0 = __builtin_bit_cast(float, a);
+    g1 = __builtin_bit_cast(float, b);
 }
 
 // ---- outer-product accumulation over the 16 samples of a tile --------------------------------------
 struct Accum {
-    f32x4 p1[4];       // [left64 tile t]            x right16
+    f32x4 p1;          // lane n: sum over samples of left64[n] * (columns 0..3 of the 16-column right tile)
+    float p1_sum;      // lane n: sum over samples of left64[n]
     f32x4 p2[4][2];    // [left64 tile t][right32 u]
     f32x4 p3[2];       // [left32 tile u]            x right16
 };
@@ -185,6 +217,8 @@ struct Accum {
 struct Addr {
     int wl64, wl32, wr32, wr16;     // byte offsets of this lane's float4 stores (row j, columns 4g..)
     int rl64[4], rl32[4], rr32[4], rr16[4];   // byte offsets of operand reads for k-step q (row 4q + g, column j)
+    int row64[4];                   // p1: word lane ^ 4k of a left64 row (k = swizzle class of the row)
+    int col4;                       // p1: column lane & 3 of the constant region
 };
 
 DEV void make_addr(Addr &ad, int j, int g) {
@@ -200,6 +234,10 @@ DEV void make_addr(Addr &ad, int j, int g) {
         ad.rr32[q] = 4 * (RIGHT_W + s * P32 + c);
         ad.rr16[q] = 4 * (RIGHT_W + s * P16 + c);
     }
+    const int lane = 16 * g + j;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ad.row64[k] = 4 * (LEFT_W + (lane ^ (4 * k)));
+    ad.col4 = 4 * (CONST_W + (lane & 3));
 }
 
 #define ST4(base, off, v) (*reinterpret_cast<f32x4 *>((base) + (off)) = (v))
@@ -215,12 +253,15 @@ DEV void park_p1(char *wb, const Addr &ad, const f32x4 (&left)[4]) {
     for (int t = 0; t < 4; ++t) ST4(wb, ad.wl64 + 64 * t, left[t]);
     __builtin_amdgcn_wave_barrier();
 }
-DEV void run_p1(Accum &ac, char *wb, const Addr &ad, const int (&rc)[4]) {
+// One 4x4-block MFMA per sample: lane n = 4b + c multiplies left64[s][n] with columns 0..3 of sample s of the
+// constant region, so every product is a wanted one (a 16x16x4 tile would spend 16 columns on these 4).
+DEV void run_p1(Accum &ac, char *wb, const Addr &ad) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const float r = LD1(wb, rc[q]);
-#pragma unroll
-        for (int t = 0; t < 4; ++t) ac.p1[t] = mfma4(LD1(wb, ad.rl64[q] + 64 * t), r, ac.p1[t]);
+    for (int s = 0; s < 16; ++s) {
+        const float l = LD1(wb, ad.row64[(s >> 1) & 3] + 4 * s * P64);
+        const float r = LD1(wb, ad.col4 + 4 * (s * P16 + swz(s)));
+        ac.p1 = mfma_blocks(r, l, ac.p1);
+        ac.p1_sum += l;
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -262,9 +303,10 @@ DEV void run_p3(Accum &ac, char *wb, const Addr &ad) {
 
 DEV void zero_accum(Accum &ac) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    ac.p1 = z;
+    ac.p1_sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        ac.p1[t] = z;
         ac.p2[t][0] = z;
         ac.p2[t][1] = z;
     }
@@ -273,16 +315,21 @@ DEV void zero_accum(Accum &ac) {
 }
 
 // p1/p2/p3 and the per-lane vectors -> this wave's row of flat critic gradients (in LDS).
-// ncol1: columns of p1 that are W1 columns (4 for the backward, 2 for the penalty); bias1_col: column of p1
-// that holds the layer-1 bias gradient (-1: none).  v4/vb*: per-lane sums (already reduced over j).
-DEV void store_row(float *row, const Accum &ac, int j, int g, int ncol1, int bias1_col) {
+// ncol1: columns of p1 that are W1 columns (4 for the backward, 2 for the penalty); bias1: p1_sum is the
+// layer-1 bias gradient.
+DEV void store_row(float *row, const Accum &ac, int j, int g, int ncol1, bool bias1) {
+    {
+        const int n = 16 * g + j;
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (c < ncol1) row[C_W1 + n * 4 + c] = ac.p1[c];
+        if (bias1) row[C_B1 + n] = ac.p1_sum;
+    }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int n = 16 * t + 4 * g + r;
-            if (j < ncol1) row[C_W1 + n * 4 + j] = ac.p1[t][r];
-            if (j == bias1_col) row[C_B1 + n] = ac.p1[t][r];
 #pragma unroll
             for (int u = 0; u < 2; ++u) row[C_W2 + (16 * u + j) * 64 + n] = ac.p2[t][u][r];
         }
@@ -371,17 +418,13 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
     char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + (WGRAD ? wave * WAVE_WORDS : 0));
     Addr ad;
     Accum ac;
-    int rc[4];          // constant-region reads: the input tile [sample][in0..3, 1, 0...]
     f32x4 db2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, db3 = {0.f, 0.f, 0.f, 0.f}, dw4 = {0.f, 0.f, 0.f, 0.f};
     float db4 = 0.f;
     if (WGRAD) {
         make_addr(ad, j, g);
         zero_accum(ac);
         float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
-        for (int k = lane; k < 256; k += 64) cst[k] = 0.f;
-        if (lane < 16) cst[lane * P16 + (4 ^ swz(lane))] = 1.f;          // column 4 = 1 -> layer-1 bias gradient
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rc[q] = 4 * (CONST_W + (4 * q + g) * P16 + (j ^ swz(4 * q + g)));
+        for (int k = lane; k < 256; k += 64) cst[k] = 0.f;            // the input tile [sample][in0..3]
     }
     const f32x4 w4 = quad(lds, Q_W4, lane);
     float ssum = 0.f;
@@ -452,7 +495,7 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
             // the input tile: column g of row j
             *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = in;
             park_p1(wbuf, ad, gz1);
-            run_p1(ac, wbuf, ad, rc);
+            run_p1(ac, wbuf, ad);
             STAMP(3)
         }
     }
@@ -469,7 +512,7 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
     }
     __syncthreads();
     float *row = lds + wave * C_SLAB;
-    store_row(row, ac, j, g, 4, 4);
+    store_row(row, ac, j, g, 4, true);
     ssum = wave_sum(ssum);
     if (lane == 0) row[C_NP] = ssum;            // extra slab column: sum of scores, reduced in a fixed order
     db2[0] = sum_over_j(db2[0]);
@@ -599,12 +642,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
     Accum ac;
     make_addr(ad, j, g);
     zero_accum(ac);
-    int rc[4];
     {
         float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
-        for (int k = lane; k < 256; k += 64) cst[k] = 0.f;     // columns 2..15 of the gh tile stay 0
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rc[q] = 4 * (CONST_W + (4 * q + g) * P16 + (j ^ swz(4 * q + g)));
+        for (int k = lane; k < 256; k += 64) cst[k] = 0.f;     // columns 2, 3 of the gh tile stay 0
     }
     f32x4 dw4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 w4 = quad(lds, Q_W4, lane);
@@ -682,13 +722,13 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
         // gh tile: column g (< 2) of row j
         if (g < 2) *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = ghb;
         park_p1(wbuf, ad, v1);
-        run_p1(ac, wbuf, ad, rc);
+        run_p1(ac, wbuf, ad);
     }
     __syncthreads();
     float *row = lds + wave * C_SLAB;
     for (int e = lane; e <= C_NP; e += 64) row[e] = 0.f;    // bias gradients and W1[:, 2:4] get no contribution
     __builtin_amdgcn_wave_barrier();
-    store_row(row, ac, j, g, 2, -1);
+    store_row(row, ac, j, g, 2, false);
     dw4 = sum_over_j(dw4);
     if (j == 0) {
 #pragma unroll
