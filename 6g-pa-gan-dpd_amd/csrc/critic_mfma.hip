@@ -109,7 +109,7 @@ DEV float sum_over_groups(float v) {
 
 // forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).  The last
 // layer (16 -> 1) runs on the VALU: four FMAs per lane and a sum over the lane groups.
-DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope) {
+DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope) {
     const f32x4 a1 = quad(img, Q_A1, lane);
 #pragma unroll
     for (int t = 0; t < 4; ++t) a.h1[t] = lrelu4(mfma4(a1[t], in, quad(img, Q_B1 + t, lane)), slope);
@@ -125,6 +125,8 @@ DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope
     }
     a.h2[0] = lrelu4(z0, slope);
     a.h2[1] = lrelu4(z1, slope);
+}
+DEV void forward_back(Acts &a, const float *img, int lane, float slope) {
     f32x4 y0 = quad(img, Q_B3, lane), y1 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 w30 = quad(img, Q_A3, lane), w31 = quad(img, Q_A3 + 1, lane);
 #pragma unroll
@@ -138,6 +140,10 @@ DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope
 #pragma unroll
     for (int r = 1; r < 4; ++r) s = __builtin_fmaf(w4[r], a.h3[r], s);
     a.score = sum_over_groups(s) + img[(Q_B4 * 64 + lane) * 4];
+}
+DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope) {
+    forward_front(a, img, lane, in, slope);
+    forward_back(a, img, lane, slope);
 }
 
 // back-propagation of an upstream vector through the three hidden layers, in two steps:
@@ -208,7 +214,7 @@ DEV void to_input(const float *img, int lane, const f32x4 (&d1)[4], float &g0, f
 
 // ---- outer-product accumulation over the 16 samples of a tile --------------------------------------
 struct Accum {
-    f32x4 p1;          // lane n: sum over samples of left64[n] * (columns 0..3 of the 16-column right tile)
+    f32x4 p1, p1b;     // lane n: sum over (even, odd) samples of left64[n] * (columns 0..3 of the right tile)
     float p1_sum;      // lane n: sum over samples of left64[n]
     f32x4 p2[4][2];    // [left64 tile t][right32 u]
     f32x4 p3[2];       // [left32 tile u]            x right16
@@ -260,7 +266,8 @@ DEV void run_p1(Accum &ac, char *wb, const Addr &ad) {
     for (int s = 0; s < 16; ++s) {
         const float l = LD1(wb, ad.row64[(s >> 1) & 3] + 4 * s * P64);
         const float r = LD1(wb, ad.col4 + 4 * (s * P16 + swz(s)));
-        ac.p1 = mfma_blocks(r, l, ac.p1);
+        if (s & 1) ac.p1b = mfma_blocks(r, l, ac.p1b);
+        else ac.p1 = mfma_blocks(r, l, ac.p1);
         ac.p1_sum += l;
     }
     __builtin_amdgcn_wave_barrier();
@@ -304,6 +311,7 @@ DEV void run_p3(Accum &ac, char *wb, const Addr &ad) {
 DEV void zero_accum(Accum &ac) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     ac.p1 = z;
+    ac.p1b = z;
     ac.p1_sum = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -322,7 +330,7 @@ DEV void store_row(float *row, const Accum &ac, int j, int g, int ncol1, bool bi
         const int n = 16 * g + j;
 #pragma unroll
         for (int c = 0; c < 4; ++c)
-            if (c < ncol1) row[C_W1 + n * 4 + c] = ac.p1[c];
+            if (c < ncol1) row[C_W1 + n * 4 + c] = ac.p1[c] + ac.p1b[c];
         if (bias1) row[C_B1 + n] = ac.p1_sum;
     }
 #pragma unroll
@@ -425,6 +433,10 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
         zero_accum(ac);
         float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
         for (int k = lane; k < 256; k += 64) cst[k] = 0.f;            // the input tile [sample][in0..3]
+        // the W1 gradient of a tile is accumulated during the next tile's forward (before the first: zeros)
+        float *left = lds + IMG_WORDS + wave * WAVE_WORDS + LEFT_W;
+        for (int k = lane; k < 16 * P64; k += 64) left[k] = 0.f;
+        __builtin_amdgcn_wave_barrier();
     }
     const f32x4 w4 = quad(lds, Q_W4, lane);
     float ssum = 0.f;
@@ -456,7 +468,9 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
 #else
 #define STAMP(k)
 #endif
-        tile_forward(a, lds, lane, in, slope);
+        forward_front(a, lds, lane, in, slope);
+        if (WGRAD) run_p1(ac, wbuf, ad);     // previous tile: parked a whole forward ago, no LDS latency left
+        forward_back(a, lds, lane, slope);
         STAMP(1)
         ssum += (valid && g == 0) ? a.score : 0.f;
         f32x4 m1[4], m2[2];
@@ -495,10 +509,10 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
             // the input tile: column g of row j
             *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = in;
             park_p1(wbuf, ad, gz1);
-            run_p1(ac, wbuf, ad);
             STAMP(3)
         }
     }
+    if (WGRAD) run_p1(ac, wbuf, ad);
 #ifdef ABL_TIMING
     if (WGRAD && lane == 0)
         for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + k, tacc[k]);
@@ -645,6 +659,10 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
     {
         float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
         for (int k = lane; k < 256; k += 64) cst[k] = 0.f;     // columns 2, 3 of the gh tile stay 0
+        // the W1 gradient of a tile is accumulated during the next tile's first MFMA block (before the first: zeros)
+        float *left = lds + IMG_WORDS + wave * WAVE_WORDS + LEFT_W;
+        for (int k = lane; k < 16 * P64; k += 64) left[k] = 0.f;
+        __builtin_amdgcn_wave_barrier();
     }
     f32x4 dw4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 w4 = quad(lds, Q_W4, lane);
@@ -701,6 +719,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
                 z1 = mfma4(w1[r], du1[t][r], z1);
             }
         }
+        run_p1(ac, wbuf, ad);                 // previous tile's v1 x gh
         f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
         // every outer-product phase is parked as soon as its factors exist and run after the next block of
         // chain MFMAs (which covers the LDS round trip): p3 = du2 x v3, p2 = du1 x v2, p1 = v1 x gh
@@ -722,8 +741,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
         // gh tile: column g (< 2) of row j
         if (g < 2) *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = ghb;
         park_p1(wbuf, ad, v1);
-        run_p1(ac, wbuf, ad);
     }
+    run_p1(ac, wbuf, ad);
     __syncthreads();
     float *row = lds + wave * C_SLAB;
     for (int e = lane; e <= C_NP; e += 64) row[e] = 0.f;    // bias gradients and W1[:, 2:4] get no contribution

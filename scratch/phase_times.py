@@ -20,12 +20,14 @@ def go():
     L.call("dpd_gen_mse_step", L.fptr(iq), B, S, L.fptr(tgt), L.fptr(wq), 0.2, 0, L.fptr(absmax), L.fptr(grads), L.fptr(loss), wsp, wsn, 2, st)
 go(); torch.cuda.synchronize()
 ws[off:off + 160].zero_()
-go(); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record(); go(); e1.record(); torch.cuda.synchronize()
+print("step %.3f ms (kernel + slab reduce)" % e0.elapsed_time(e1))
 t = ws[off:off + 160].view(torch.int64).cpu().tolist()
-t = t[:13] + [t[13 if False else 13]] + t[14:] if False else t
 pairs = B * 16 * 2   # tile pairs in the launch
-names = ["prefetch+div", "F1", "S1A", "S1B+V1A", "S2A+V1B", "S2B+V2A", "S3A+V2B", "S3B", "V3P", "S4AB+V4A", "S5A+V4B", "S5B+V5A", "S6A+V5B", "S6B", "-", "-", "commit", "vmwait", "looptail", "-"]
+names = ["prefetch+div", "F1", "S1A", "S1B+V1A", "S2A+V1B", "S2B+V2A", "V2B+V3+V4A", "S5A+V4B", "S5B+V5A", "S6A+V5B", "S6B", "-", "-", "-", "-", "-", "commit", "vmwait", "looptail", "-"]
 tot = sum(t)
 for n, v in zip(names, t):
     print("%-10s %8.1f cycles/pair  %5.1f%%" % (n, v / pairs, 100 * v / tot))
+print("counter rate if the waves run the whole kernel: %.2f GHz" % (tot / (B * 16 * 2) * (B * 16 * 2 / 2048) / (e0.elapsed_time(e1) * 1e-3) / 1e9))
 print("total %.1f cycles/pair (100 MHz counter units if s_memtime is the constant-rate clock)" % (tot / pairs))
