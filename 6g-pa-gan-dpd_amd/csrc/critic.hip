@@ -29,6 +29,7 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
 // kernel family: 0 = by size (MFMA from 1024 samples), 1 = VALU, 2 = MFMA
 static int g_critic_impl = 0;
 extern int g_gen_deterministic;
+extern int g_critic_deterministic;
 static bool critic_use_mfma(int64_t N) { return g_critic_impl == 2 || (g_critic_impl == 0 && N >= 1024); }
 
 extern "C" int dpd_set_option(const char *name, int value) {
@@ -39,6 +40,10 @@ extern "C" int dpd_set_option(const char *name, int value) {
     }
     if (__builtin_strcmp(name, "gen_deterministic") == 0 && (value == 0 || value == 1)) {
         g_gen_deterministic = value;
+        return DPD_OK;
+    }
+    if (__builtin_strcmp(name, "critic_deterministic") == 0 && (value == 0 || value == 1)) {
+        g_critic_deterministic = value;
         return DPD_OK;
     }
     dpd_set_error("set_option: unknown option %s or bad value %d", name, value);
@@ -451,7 +456,7 @@ extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N,
     }
     if (critic_use_mfma(N))
         return critic_mfma_backward(x, cond, N, wb, slope, gscore, gconst, grads, gx, score_sum,
-                                    reinterpret_cast<float *>(ws), st);
+                                    reinterpret_cast<float *>(grads || ws_bytes >= 64 ? ws : nullptr), st);
     const int grid = grid_for(N, TPB, 1024);
     float *slab = reinterpret_cast<float *>(ws);
     constexpr size_t lds_bytes = (size_t)(C_NP + 3 + TPB * LP + TPB * RP) * sizeof(float);

@@ -366,6 +366,53 @@ DEV void combine_rows(float *lds, float *slab_row) {
         slab_row[e] = (lds[e] + lds[C_SLAB + e]) + (lds[2 * C_SLAB + e] + lds[3 * C_SLAB + e]);
 }
 
+// ---- tile hand-out ----------------------------------------------------------------------------------
+// Units of UNIT consecutive tiles are handed out through a device counter, first come, first served: CUs
+// run these kernels at visibly different speeds (per-wave run times of one launch spread by +-13% under
+// a fixed assignment), and the launch ends with its slowest wave.  The counter is bumped one unit ahead
+// with a hand-issued atomic (lane 0 only: the asm narrows exec itself, so no branch and no merge of
+// register values surrounds it) whose result stays in next_raw until the unit is started; the
+// compiler's own atomic sequence waits for the round trip at once.  The compiler does not count this
+// load, hence the explicit wait before the value is read (wait and read are one asm statement, and the
+// atomic takes next_raw as an in/out operand: no copy of the register between the issue and the wait).
+// queue == NULL: units in a fixed round-robin order (results then do not depend on timing).  The first
+// unit of a wave is its own index.  The loops that use this are wave-uniform (all lanes active).
+struct TileQueue {
+    static constexpr unsigned UNIT = 8;
+    unsigned *queue;
+    unsigned n_waves, static_next, unit, in_unit, next_raw;
+    DEV void init(unsigned *q, unsigned first, unsigned waves) {
+        queue = q;
+        n_waves = waves;
+        static_next = first;
+        unit = first;
+        in_unit = 0;
+        next_raw = 0;
+    }
+    DEV int64_t tile() const { return (int64_t)unit * UNIT + in_unit; }
+    DEV void advance(int lane) {
+        if (in_unit == 1 && queue != nullptr) {
+            const unsigned one = 1u;
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                         : "+v"(next_raw), "=&s"(saved)
+                         : "v"(queue), "v"(one)
+                         : "memory");
+        }
+        if (++in_unit == UNIT) {
+            in_unit = 0;
+            if (queue != nullptr) {
+                unsigned raw;   // wait and read in one statement: nothing can read the register in between
+                asm volatile("s_waitcnt vmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(raw) : "v"(next_raw) : "memory");
+                unit = n_waves + raw;
+            } else {
+                unit = n_waves + static_next;
+                static_next += n_waves;
+            }
+        }
+    }
+};
+
 // ------------------------------------------------------------------------------------- kernels
 #ifndef NOGRAD_WAVES
 #define NOGRAD_WAVES 2      // measured: 3 waves per SIMD (168 registers, ~35 spilled) is 7% slower on the Stage-2 step
@@ -419,7 +466,7 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
                                                                 int64_t N, const float *__restrict__ wb, float slope,
                                                                 const float *__restrict__ gscore, float gconst,
                                                                 float2 *__restrict__ gx, float *__restrict__ slab,
-                                                                float *__restrict__ score_sum) {
+                                                                float *__restrict__ score_sum, unsigned *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // WGRAD: LDS_WORDS (> 64 KiB), else IMG_WORDS
     build_image(lds, wb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
@@ -440,12 +487,15 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
     }
     const f32x4 w4 = quad(lds, Q_W4, lane);
     float ssum = 0.f;
+#if defined(ABL_TIMING) || defined(ABL_CLOCK)
+    // experiment: shader-clock cycles and 100 MHz ticks between here and the end of the wave's loop
+    const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef ABL_TIMING
-    unsigned long long tacc[6] = {0}, tlast = __builtin_readcyclecounter();
+    unsigned long long tacc[6] = {0}, tlast = clk0;
 #endif
     const int64_t ntiles = (N + 15) >> 4;
     // the tile's input (and upstream gradient) is loaded one tile ahead
-    const int64_t stride = (int64_t)gridDim.x * WAVES;
     auto fetch_in = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
         return (tile < ntiles && n < N) ? (g < 2 ? x[2 * n + g] : cond[2 * n + g - 2]) : 0.f;
@@ -454,13 +504,18 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
         const int64_t n = tile * 16 + j;
         return (tile < ntiles && n < N) ? (gscore ? gscore[n] : gconst) : 0.f;
     };
-    float in_next = fetch_in((int64_t)blockIdx.x * WAVES + wave), gs_next = fetch_gs((int64_t)blockIdx.x * WAVES + wave);
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
+    TileQueue tq;
+    tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES);
+    int64_t tile = tq.tile();
+    float in_next = fetch_in(tile), gs_next = fetch_gs(tile);
+    while (tile < ntiles) {
         const int64_t n = tile * 16 + j;
         const bool valid = n < N;
         const float in = in_next, gs = gs_next;
-        in_next = fetch_in(tile + stride);
-        gs_next = fetch_gs(tile + stride);
+        tq.advance(lane);
+        tile = tq.tile();
+        in_next = fetch_in(tile);
+        gs_next = fetch_gs(tile);
         Acts a;
 #ifdef ABL_TIMING
 #define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long now = __builtin_readcyclecounter(); tacc[k] += now - tlast; tlast = now; __builtin_amdgcn_sched_barrier(0); }
@@ -517,6 +572,14 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
     if (WGRAD && lane == 0)
         for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + k, tacc[k]);
 #endif
+#if defined(ABL_TIMING) || defined(ABL_CLOCK)
+    if (WGRAD && lane == 0) {   // slots 6, 7: their ratio is the shader clock in units of 100 MHz
+        atomicAdd(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + 6, __builtin_readcyclecounter() - clk0);
+        atomicAdd(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + 7, __builtin_amdgcn_s_memrealtime() - real0);
+        atomicMax(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + 8, __builtin_amdgcn_s_memrealtime() - real0);
+        atomicMin(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + 9, __builtin_amdgcn_s_memrealtime() - real0);
+    }
+#endif
     if (!WGRAD) {
         if (score_sum) {   // no slab in this variant: one atomic per wave (order-dependent in the last bits)
             ssum = wave_sum(ssum);
@@ -554,14 +617,13 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
                                                           const float *__restrict__ cond, const float *__restrict__ alpha,
                                                           int64_t N, int64_t L, const float *__restrict__ wb, float slope,
                                                           float2 *__restrict__ gout, unsigned *__restrict__ maskw,
-                                                          float *__restrict__ tile_sq) {
+                                                          float *__restrict__ tile_sq, unsigned *__restrict__ queue) {
     __shared__ __attribute__((aligned(16))) float lds[IMG_WORDS];
     build_image(lds, wb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const f32x4 w4 = quad(lds, Q_W4, lane);
     const int64_t ntiles = (N + 15) >> 4;
     // the tile's input is loaded one tile ahead
-    const int64_t stride = (int64_t)gridDim.x * WAVES;
     auto fetch = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
         float in = 0.f;
@@ -575,12 +637,18 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         }
         return in;
     };
-    float in_next = fetch((int64_t)blockIdx.x * WAVES + wave);
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
+    TileQueue tq;
+    tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES);
+    int64_t tile_next = tq.tile();
+    float in_next = fetch(tile_next);
+    while (tile_next < ntiles) {
+        const int64_t tile = tile_next;
         const int64_t n = tile * 16 + j;
         const bool valid = n < N;
         const float in = in_next;
-        in_next = fetch(tile + stride);
+        tq.advance(lane);
+        tile_next = tq.tile();
+        in_next = fetch(tile_next);
         Acts a;
         tile_forward(a, lds, lane, in, slope);
         f32x4 m1[4], m2[2];
@@ -647,7 +715,7 @@ template <bool ROW1>
 __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restrict__ gin, const unsigned *__restrict__ maskw,
                                                           const float *__restrict__ rowc, int64_t N, int64_t L,
                                                           const float *__restrict__ wb, float slope,
-                                                          float *__restrict__ slab) {
+                                                          float *__restrict__ slab, unsigned *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // LDS_WORDS
     build_image(lds, wb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
@@ -669,7 +737,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
     const f32x4 a1 = quad(lds, Q_A1, lane);
     const int64_t ntiles = (N + 15) >> 4;
     // the tile's mask word, input gradient and row coefficient are loaded one tile ahead
-    const int64_t stride = (int64_t)gridDim.x * WAVES;
     unsigned bits_next = 0u;
     float2 gh_next = make_float2(0.f, 0.f);
     auto fetch = [&](int64_t tile) {
@@ -685,11 +752,16 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
             }
         }
     };
-    fetch((int64_t)blockIdx.x * WAVES + wave);
-    for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
+    TileQueue tq;
+    tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES);
+    int64_t tile = tq.tile();
+    fetch(tile);
+    while (tile < ntiles) {
         const unsigned bits = bits_next;
         const float gh0 = gh_next.x, gh1 = gh_next.y;
-        fetch(tile + stride);
+        tq.advance(lane);
+        tile = tq.tile();
+        fetch(tile);
         f32x4 m1[4], m2[2], m3;
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -791,29 +863,47 @@ int critic_mfma_forward(const float *x, const float *cond, int64_t N, const floa
     return DPD_OK;
 }
 
+int g_critic_deterministic = 0;   // dpd_set_option("critic_deterministic", 0 / 1)
+
+// the tile counter of a launch: one zeroed word of the caller's workspace (NULL: fixed tile order)
+static int tile_counter(unsigned *word, hipStream_t st, unsigned **out) {
+    *out = nullptr;
+    if (g_critic_deterministic || !word) return DPD_OK;
+    DPD_HIP(hipMemsetAsync(word, 0, 2 * sizeof(unsigned), st));
+    *out = word;
+    return DPD_OK;
+}
+
 int critic_mfma_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope, const float *gscore,
                          float gconst, float *grads, float *gx, float *score_sum, float *ws, hipStream_t st) {
     float2 *gx2 = reinterpret_cast<float2 *>(gx);
     int rc = init_attrs();
     if (rc) return rc;
+    unsigned *queue;
     if (!grads) {
+        // no slab in this variant: the workspace, when there is one, only holds the counter
+        rc = tile_counter(reinterpret_cast<unsigned *>(ws), st, &queue);
+        if (rc) return rc;
         hipLaunchKernelGGL((k_critic_bwd_mfma<false, true>), dim3(grid_tiles(N, 4)), dim3(WAVES * 64), IMG_LDS, st, x, cond, N, wb,
-                           slope, gscore, gconst, gx2, nullptr, score_sum);
+                           slope, gscore, gconst, gx2, nullptr, score_sum, queue);
         DPD_LAUNCH_CHECK();
         return DPD_OK;
     }
     const int grid = grid_tiles(N, 2);
+    rc = tile_counter(reinterpret_cast<unsigned *>(ws + (size_t)512 * C_SLAB), st, &queue);   // behind the slab rows
+    if (rc) return rc;
     if (gx)
         hipLaunchKernelGGL((k_critic_bwd_mfma<true, true>), dim3(grid), dim3(WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
-                           gscore, gconst, gx2, ws, score_sum);
+                           gscore, gconst, gx2, ws, score_sum, queue);
     else
         hipLaunchKernelGGL((k_critic_bwd_mfma<true, false>), dim3(grid), dim3(WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
-                           gscore, gconst, gx2, ws, score_sum);
+                           gscore, gconst, gx2, ws, score_sum, queue);
     DPD_LAUNCH_CHECK();
     return gen_reduce_slab_generic(ws, grid, C_SLAB, C_NP, grads, score_sum, 1.f, st);
 }
 
-// ws layout: slab (512 rows) | mask words [ntiles * 64] | g [N] float2 | tile_sq [ntiles] | rowc [B] | pen [B]
+// ws layout: slab (512 rows) | mask words [ntiles * 64] | g [N] float2 | tile_sq [ntiles] | rowc [B] | pen [B] |
+//            tile counters of pass A and pass C (inside the 1024 spare bytes)
 size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L) {
     const int64_t N = B * L, nt = (N + 15) >> 4;
     return (size_t)512 * C_SLAB * 4 + (size_t)nt * 64 * 4 + (size_t)N * 8 + (size_t)nt * 4 + (size_t)B * 8 + 1024;
@@ -829,17 +919,22 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
     float2 *g = reinterpret_cast<float2 *>(base + off); off += (size_t)N * 8;
     float *tile_sq = reinterpret_cast<float *>(base + off); off += (size_t)nt * 4;
     float *rowc = reinterpret_cast<float *>(base + off); off += (size_t)B * 4;
-    float *pen = reinterpret_cast<float *>(base + off);
+    float *pen = reinterpret_cast<float *>(base + off); off += (size_t)B * 4;
+    unsigned *counters = reinterpret_cast<unsigned *>(base + ((off + 63) & ~(size_t)63));
     const bool row1 = (L == 1);
     int rc = init_attrs();
     if (rc) return rc;
+    unsigned *queue;
+    rc = tile_counter(counters, st, &queue);
+    if (rc) return rc;
+    unsigned *queue_c = queue ? queue + 1 : nullptr;
     const int ga = grid_tiles(N, 4);
     if (row1)
         hipLaunchKernelGGL((k_gp_a_mfma<true>), dim3(ga), dim3(WAVES * 64), 0, st, real, fake, cond, alpha, N, L, wb, slope,
-                           g, maskw, tile_sq);
+                           g, maskw, tile_sq, queue);
     else
         hipLaunchKernelGGL((k_gp_a_mfma<false>), dim3(ga), dim3(WAVES * 64), 0, st, real, fake, cond, alpha, N, L, wb, slope,
-                           g, maskw, tile_sq);
+                           g, maskw, tile_sq, queue);
     DPD_LAUNCH_CHECK();
     if (row1)
         hipLaunchKernelGGL(k_gp_rows_single, dim3(grid_for(B, 256, 1024)), dim3(256), 0, st, g, B, rownorm, rowc, pen);
@@ -850,9 +945,9 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
     DPD_LAUNCH_CHECK();
     const int gc = grid_tiles(N, 2);
     if (row1)
-        hipLaunchKernelGGL((k_gp_c_mfma<true>), dim3(gc), dim3(WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab);
+        hipLaunchKernelGGL((k_gp_c_mfma<true>), dim3(gc), dim3(WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab, queue_c);
     else
-        hipLaunchKernelGGL((k_gp_c_mfma<false>), dim3(gc), dim3(WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab);
+        hipLaunchKernelGGL((k_gp_c_mfma<false>), dim3(gc), dim3(WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab, queue_c);
     DPD_LAUNCH_CHECK();
     return gen_reduce_slab_generic(slab, gc, C_SLAB, C_NP, grads, nullptr, 1.f, st);
 }

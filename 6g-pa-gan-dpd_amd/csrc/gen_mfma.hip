@@ -473,13 +473,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #pragma unroll
         for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
     };
-    auto S1 = [&](Tile &t, const float (&b)[8]) {
-        t.a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
-        t.a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto S1 = [&](f32x4 &a0, f32x4 &a1, const float (&b)[8]) {
+        a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
+        a1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            t.a0 = mfma4(w.A1[0][s], b[s], t.a0);
-            t.a1 = mfma4(w.A1[1][s], b[s], t.a1);
+            a0 = mfma4(w.A1[0][s], b[s], a0);
+            a1 = mfma4(w.A1[1][s], b[s], a1);
         }
     };
     auto V1 = [&](Tile &t, int buf) {
@@ -602,9 +602,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             dW2[1] = mfma4(hb, g2, dW2[1]);
         }
     };
+#if defined(ABL_TIMING) || defined(ABL_CLOCK)
+    // experiment: shader-clock cycles and 100 MHz ticks between here and the end of the wave's loop
+    const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = __builtin_amdgcn_s_memrealtime();
+#endif
 #ifdef ABL_TIMING
     // experiment: cycles between phase boundaries, summed per wave and added into queue[16 + k]
-    unsigned long long tacc[20] = {0}, tlast = __builtin_readcyclecounter();
+    unsigned long long tacc[20] = {0}, tlast = clk0;
     int tk = 0;
 #define PHASE()                                            \
     {                                                      \
@@ -686,6 +690,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
         }
         __builtin_amdgcn_wave_barrier();
+        // (measured: starting FC1 of the second pair inside the output stage of the first, the one stretch
+        // of a pair without MFMA work of its own, is 3% slower: the MFMAs hold up the VALU work behind them)
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             // tiles beyond L inside a started pair run with zero upstream gradient: they add nothing
@@ -700,9 +706,9 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             F1(bA, cA);
             F1(bB, cB);
             PHASE();
-            S1(A, bA);
+            S1(A.a0, A.a1, bA);
             PHASE();
-            S1(B, bB);
+            S1(B.a0, B.a1, bB);
             V1(A, 0);
             PHASE();
             S2(A);
@@ -732,6 +738,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #ifdef ABL_TIMING
     if (lane == 0)
         for (int k = 0; k < 20; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(queue + 16) + k, tacc[k]);
+#endif
+#if defined(ABL_TIMING) || defined(ABL_CLOCK)
+    if (lane == 0) {   // slots 20, 21: their ratio is the shader clock in units of 100 MHz
+        atomicAdd(reinterpret_cast<unsigned long long *>(queue + 16) + 20, __builtin_readcyclecounter() - clk0);
+        atomicAdd(reinterpret_cast<unsigned long long *>(queue + 16) + 21, __builtin_amdgcn_s_memrealtime() - real0);
+    }
 #endif
 
     // ---- partial gradient row of this wave -> LDS, the workgroup's four rows are summed, one row per

@@ -19,11 +19,13 @@ off = 1024 * 1560 * 4 + 64
 def go():
     L.call("dpd_gen_mse_step", L.fptr(iq), B, S, L.fptr(tgt), L.fptr(wq), 0.2, 0, L.fptr(absmax), L.fptr(grads), L.fptr(loss), wsp, wsn, 2, st)
 go(); torch.cuda.synchronize()
-ws[off:off + 160].zero_()
+ws[off:off + 176].zero_()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record(); go(); e1.record(); torch.cuda.synchronize()
 print("step %.3f ms (kernel + slab reduce)" % e0.elapsed_time(e1))
-t = ws[off:off + 160].view(torch.int64).cpu().tolist()
+t = ws[off:off + 176].view(torch.int64).cpu().tolist()
+clk, real = t[20], t[21]; t = t[:20]
+print('shader clock while the waves ran: %.3f GHz; wave alive %.3f ms on average' % (clk / real * 0.1, real / 2048 / 1e5))
 pairs = B * 16 * 2   # tile pairs in the launch
 names = ["prefetch+div", "F1", "S1A", "S1B+V1A", "S2A+V1B", "S2B+V2A", "V2B+V3+V4A", "S5A+V4B", "S5B+V5A", "S6A+V5B", "S6B", "-", "-", "-", "-", "-", "commit", "vmwait", "looptail", "-"]
 tot = sum(t)

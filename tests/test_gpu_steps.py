@@ -151,3 +151,42 @@ def test_generator_gradients_bitwise_reproducible_in_deterministic_mode():
     c = grads()
     assert torch.equal(a, b)
     close(c, a.cpu().numpy(), rtol=1e-4, atol=1e-6 * float(a.abs().max()))
+
+
+@pytest.mark.gpu
+def test_critic_gradients_bitwise_reproducible_in_deterministic_mode():
+    """dpd_set_option("critic_deterministic", 1): tiles go to waves in a fixed order, two launches of the critic
+    backward and of the gradient penalty give identical bits; the default (tiles handed out first come, first
+    served) agrees to fp32 summation order."""
+    from dpd_amd import _lib as L
+    torch.manual_seed(5)
+    B, Lr = 96, 1024
+    N = B * Lr
+    x = (torch.randn(N, 2, device=DEV) * 0.3).contiguous()
+    y = (torch.randn(N, 2, device=DEV) * 0.3).contiguous()
+    c = (torch.randn(N, 2, device=DEV) * 0.3).contiguous()
+    alpha = torch.rand(B, device=DEV)
+    wb = torch.randn(2945, device=DEV) * 0.2
+    ws, wsp, wsn = L.workspace(DEV, N)
+    st = L.stream()
+
+    def run():
+        g = torch.empty(2945, device=DEV)
+        gg = torch.empty(2945, device=DEV)
+        ssum = torch.zeros(1, device=DEV)
+        gp = torch.zeros(1, device=DEV)
+        rn = torch.empty(B, device=DEV)
+        L.call("dpd_critic_backward", L.fptr(x), L.fptr(c), N, L.fptr(wb), 0.2, L.c_p(0), 1.0 / N, L.fptr(g), L.c_p(0),
+               L.fptr(ssum), wsp, wsn, st)
+        L.call("dpd_critic_gp", L.fptr(x), L.fptr(y), L.fptr(c), L.fptr(alpha), B, Lr, L.fptr(wb), 0.2, L.fptr(gp),
+               L.fptr(rn), L.fptr(gg), wsp, wsn, st)
+        torch.cuda.synchronize()
+        return torch.cat([g, gg, ssum, gp])
+    L.call("dpd_set_option", b"critic_deterministic", 1)
+    try:
+        a, b = run(), run()
+    finally:
+        L.call("dpd_set_option", b"critic_deterministic", 0)
+    d = run()
+    assert torch.equal(a, b)
+    close(d, a.cpu().numpy(), rtol=1e-4, atol=2e-6 * float(a.abs().max()))
