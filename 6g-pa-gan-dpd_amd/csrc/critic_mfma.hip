@@ -23,6 +23,12 @@ DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16
 DEV f32x4 mfma_blocks(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
 
 constexpr int WAVES = 4;
+// waves per workgroup of the weight-gradient kernels: one operand image serves all of them, so a large
+// workgroup is what lets a third wave per SIMD fit into the LDS (12: 146 KiB, one workgroup per CU)
+#ifndef WG_WAVES
+#define WG_WAVES 4
+#endif
+constexpr int WG_PER_CU = WG_WAVES == 4 ? 2 : 1;
 // operand image: quads of four consecutive k-steps per lane
 constexpr int Q_A1 = 0;     // [t]            e = t : W1[16t + i][g]
 constexpr int Q_A2 = 1;     // [u][t]         e = r : W2[16u + i][16t + 4g + r]
@@ -41,13 +47,13 @@ constexpr int IMG_WORDS = NQUAD * 64 * 4;          // 9728
 constexpr int P64 = 80, P32 = 48, P16 = 16;        // row pitches: 16 mod 32 -> rows s, s+1 hit different bank halves
 constexpr int LEFT_W = 0, RIGHT_W = 16 * P64, CONST_W = RIGHT_W + 16 * P32;
 constexpr int WAVE_WORDS = CONST_W + 16 * P16;     // 2304
-constexpr int LDS_WORDS = IMG_WORDS + WAVES * WAVE_WORDS;
-static_assert(LDS_WORDS >= WAVES * C_SLAB, "gradient rows are combined in the same LDS");
+constexpr int LDS_WORDS = IMG_WORDS + WG_WAVES * WAVE_WORDS;
+static_assert(LDS_WORDS >= WG_WAVES * C_SLAB, "gradient rows are combined in the same LDS");
 
 DEV int swz(int s) { return 4 * ((s >> 1) & 3); }
 
 DEV void build_image(float *img, const float *__restrict__ wb) {
-    for (int idx = threadIdx.x; idx < NQUAD * 64; idx += WAVES * 64) {
+    for (int idx = threadIdx.x; idx < NQUAD * 64; idx += blockDim.x) {
         const int q = idx >> 6, lane = idx & 63, i = lane & 15, g = lane >> 4;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -110,19 +116,37 @@ DEV float sum_over_groups(float v) {
 // forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).  The last
 // layer (16 -> 1) runs on the VALU: four FMAs per lane and a sum over the lane groups.
 DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope) {
+    // The operand quads of every MFMA group are read from the image one group ahead (the fences keep
+    // the compiler from sinking the reads to their first use, where their LDS latency would be exposed).
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
     const f32x4 a1 = quad(img, Q_A1, lane);
+    f32x4 b1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a.h1[t] = lrelu4(mfma4(a1[t], in, quad(img, Q_B1 + t, lane)), slope);
+    for (int t = 0; t < 4; ++t) b1[t] = quad(img, Q_B1 + t, lane);
     f32x4 z0 = quad(img, Q_B2, lane), z1 = quad(img, Q_B2 + 1, lane);
+    f32x4 w0 = quad(img, Q_A2, lane), w1 = quad(img, Q_A2 + 4, lane);
+    FENCE();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(a1[t], in, b1[t]);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        const f32x4 w0 = quad(img, Q_A2 + t, lane), w1 = quad(img, Q_A2 + 4 + t, lane);
+        f32x4 n0 = w0, n1 = w1;
+        if (t < 3) {
+            n0 = quad(img, Q_A2 + t + 1, lane);
+            n1 = quad(img, Q_A2 + 4 + t + 1, lane);
+        }
+        FENCE();
+        a.h1[t] = lrelu4(a.h1[t], slope);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z0 = mfma4(w0[r], a.h1[t][r], z0);
             z1 = mfma4(w1[r], a.h1[t][r], z1);
         }
+        FENCE();
+        w0 = n0;
+        w1 = n1;
     }
+#undef FENCE
     a.h2[0] = lrelu4(z0, slope);
     a.h2[1] = lrelu4(z1, slope);
 }
@@ -362,8 +386,13 @@ DEV float sum_over_j1(float v) {
 
 DEV void combine_rows(float *lds, float *slab_row) {
     __syncthreads();
-    for (int e = threadIdx.x; e <= C_NP; e += WAVES * 64)
-        slab_row[e] = (lds[e] + lds[C_SLAB + e]) + (lds[2 * C_SLAB + e] + lds[3 * C_SLAB + e]);
+    for (int e = threadIdx.x; e <= C_NP; e += blockDim.x) {
+        float acc = 0.f;
+#pragma unroll
+        for (int w = 0; w < WG_WAVES; w += 4)
+            acc += (lds[w * C_SLAB + e] + lds[(w + 1) * C_SLAB + e]) + (lds[(w + 2) * C_SLAB + e] + lds[(w + 3) * C_SLAB + e]);
+        slab_row[e] = acc;
+    }
 }
 
 // ---- tile hand-out ----------------------------------------------------------------------------------
@@ -462,7 +491,7 @@ __global__ __launch_bounds__(256) void k_sum_partials(const float *__restrict__ 
 }
 
 template <bool WGRAD, bool DX>
-__global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic_bwd_mfma(const float *__restrict__ x, const float *__restrict__ cond,
+__global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU : NOGRAD_WAVES) void k_critic_bwd_mfma(const float *__restrict__ x, const float *__restrict__ cond,
                                                                 int64_t N, const float *__restrict__ wb, float slope,
                                                                 const float *__restrict__ gscore, float gconst,
                                                                 float2 *__restrict__ gx, float *__restrict__ slab,
@@ -505,7 +534,8 @@ __global__ __launch_bounds__(WAVES * 64, WGRAD ? 2 : NOGRAD_WAVES) void k_critic
         return (tile < ntiles && n < N) ? (gscore ? gscore[n] : gconst) : 0.f;
     };
     TileQueue tq;
-    tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES);
+    constexpr int NW = WGRAD ? WG_WAVES : WAVES;
+    tq.init(queue, blockIdx.x * NW + wave, gridDim.x * NW);
     int64_t tile = tq.tile();
     float in_next = fetch_in(tile), gs_next = fetch_gs(tile);
     while (tile < ntiles) {
@@ -712,7 +742,7 @@ __global__ __launch_bounds__(256) void k_gp_rows_single(const float2 *__restrict
 
 // pass C: reverse chain with gh = c_row * g and the weight gradient
 template <bool ROW1>
-__global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restrict__ gin, const unsigned *__restrict__ maskw,
+__global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const float2 *__restrict__ gin, const unsigned *__restrict__ maskw,
                                                           const float *__restrict__ rowc, int64_t N, int64_t L,
                                                           const float *__restrict__ wb, float slope,
                                                           float *__restrict__ slab, unsigned *__restrict__ queue) {
@@ -753,7 +783,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
         }
     };
     TileQueue tq;
-    tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES);
+    tq.init(queue, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES);
     int64_t tile = tq.tile();
     fetch(tile);
     while (tile < ntiles) {
@@ -828,8 +858,11 @@ __global__ __launch_bounds__(WAVES * 64) void k_gp_c_mfma(const float2 *__restri
     combine_rows(lds, slab + (int64_t)blockIdx.x * C_SLAB);
 }
 
-int grid_tiles(int64_t N, int per_cu) {
-    int64_t blocks = (((N + 15) >> 4) + WAVES - 1) / WAVES;
+int grid_tiles(int64_t N, int per_cu, int waves = WAVES) {
+    int64_t blocks = (((N + 15) >> 4) + waves - 1) / waves;
+#ifdef ABL_ONE_WAVE
+    per_cu = 1;   // experiment: one workgroup per CU, i.e. every wave has its SIMD to itself
+#endif
     if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     return (int)(blocks < 1 ? 1 : blocks);
 }
@@ -889,14 +922,14 @@ int critic_mfma_backward(const float *x, const float *cond, int64_t N, const flo
         DPD_LAUNCH_CHECK();
         return DPD_OK;
     }
-    const int grid = grid_tiles(N, 2);
+    const int grid = grid_tiles(N, WG_PER_CU, WG_WAVES);
     rc = tile_counter(reinterpret_cast<unsigned *>(ws + (size_t)512 * C_SLAB), st, &queue);   // behind the slab rows
     if (rc) return rc;
     if (gx)
-        hipLaunchKernelGGL((k_critic_bwd_mfma<true, true>), dim3(grid), dim3(WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
+        hipLaunchKernelGGL((k_critic_bwd_mfma<true, true>), dim3(grid), dim3(WG_WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
                            gscore, gconst, gx2, ws, score_sum, queue);
     else
-        hipLaunchKernelGGL((k_critic_bwd_mfma<true, false>), dim3(grid), dim3(WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
+        hipLaunchKernelGGL((k_critic_bwd_mfma<true, false>), dim3(grid), dim3(WG_WAVES * 64), BIG_LDS, st, x, cond, N, wb, slope,
                            gscore, gconst, gx2, ws, score_sum, queue);
     DPD_LAUNCH_CHECK();
     return gen_reduce_slab_generic(ws, grid, C_SLAB, C_NP, grads, score_sum, 1.f, st);
@@ -943,11 +976,11 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
     DPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, pen, (int)B, gp, 1.0f / (float)B);
     DPD_LAUNCH_CHECK();
-    const int gc = grid_tiles(N, 2);
+    const int gc = grid_tiles(N, WG_PER_CU, WG_WAVES);
     if (row1)
-        hipLaunchKernelGGL((k_gp_c_mfma<true>), dim3(gc), dim3(WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab, queue_c);
+        hipLaunchKernelGGL((k_gp_c_mfma<true>), dim3(gc), dim3(WG_WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab, queue_c);
     else
-        hipLaunchKernelGGL((k_gp_c_mfma<false>), dim3(gc), dim3(WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab, queue_c);
+        hipLaunchKernelGGL((k_gp_c_mfma<false>), dim3(gc), dim3(WG_WAVES * 64), BIG_LDS, st, g, maskw, rowc, N, L, wb, slope, slab, queue_c);
     DPD_LAUNCH_CHECK();
     return gen_reduce_slab_generic(slab, gc, C_SLAB, C_NP, grads, nullptr, 1.f, st);
 }

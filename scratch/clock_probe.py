@@ -53,9 +53,9 @@ goc(); torch.cuda.synchronize()
 ws[offc:offc + 80].zero_(); ws[offc + 72:offc + 80] = 127
 ms = timed(goc, reps)
 t = ws[offc:offc + 80].view(torch.int64).cpu().tolist()
-print('critic wave alive: mean %.3f ms, max %.3f ms, min %.3f ms' % (t[7] / (reps + 1) / 2048 / 1e5, t[8] / 1e5, t[9] / 1e5))
+print('critic wave alive: mean %.3f ms, max %.3f ms, min %.3f ms' % (t[7] / (reps + 1) / int(__import__("os").environ.get("CRITIC_WAVES", "2048")) / 1e5, t[8] / 1e5, t[9] / 1e5))
 clk, real = t[6], t[7]
 ghz = clk / real * 0.1
-cyc_tile = clk / (reps + 1) / 2048 / (N / 16 / 2048)
+nwv = int(__import__("os").environ.get("CRITIC_WAVES", "2048")); cyc_tile = clk / (reps + 1) / nwv / (N / 16 / nwv)
 print("critic backward %.3f ms; shader clock %.3f GHz; %.0f cycles per tile per wave; MFMA pipe busy %.3f (124 MFMAs x 32 + 16 x 8 cycles, x 2 waves)"
       % (ms, ghz, cyc_tile, (124 * 32 + 16 * 8) * 2 / cyc_tile))
