@@ -113,113 +113,175 @@ DEV float sum_over_groups(float v) {
     return __builtin_bit_cast(float, w0) + __builtin_bit_cast(float, w1);
 }
 
-// forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).  The last
-// layer (16 -> 1) runs on the VALU: four FMAs per lane and a sum over the lane groups.
-DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope) {
-    // The operand quads of every MFMA group are read from the image one group ahead (the fences keep
-    // the compiler from sinking the reads to their first use, where their LDS latency would be exposed).
+// ---- operand prefetch ---------------------------------------------------------------------------------
+// The weights live in the LDS image and are read per tile.  Every MFMA group takes its operand quads as
+// arguments that the caller (or the previous group, through the `pre` callable) has read one group
+// earlier, so the LDS latency of a read is covered by the MFMAs of the group before it.  The fences keep
+// the compiler from sinking those reads down to their first use.
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
-    const f32x4 a1 = quad(img, Q_A1, lane);
-    f32x4 b1[4];
+struct NoPre {
+    DEV void operator()() const {}
+};
+struct FrontOps {      // FC1 weights, FC2 accumulator start (b2) and the first FC2 weight pair
+    f32x4 a1, b2[2], w0, w1;
+};
+struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 for the VALU last layer
+    f32x4 b3, w30, w31, w4;
+};
+struct TopOps {        // W3^T
+    f32x4 t0, t1;
+};
+struct BotOps {        // W2^T, first half (u = 0)
+    f32x4 w[4];
+};
+struct InOps {         // W1[:, 0:2] per neuron, VALU operands
+    f32x4 w0[4], w1[4];
+};
+DEV void load_ops(FrontOps &o, const float *img, int lane) {
+    o.a1 = quad(img, Q_A1, lane);
+    o.b2[0] = quad(img, Q_B2, lane);
+    o.b2[1] = quad(img, Q_B2 + 1, lane);
+    o.w0 = quad(img, Q_A2, lane);
+    o.w1 = quad(img, Q_A2 + 4, lane);
+}
+DEV void load_ops(Fc3Ops &o, const float *img, int lane) {
+    o.b3 = quad(img, Q_B3, lane);
+    o.w30 = quad(img, Q_A3, lane);
+    o.w31 = quad(img, Q_A3 + 1, lane);
+    o.w4 = quad(img, Q_W4, lane);
+}
+DEV void load_ops(TopOps &o, const float *img, int lane) {
+    o.t0 = quad(img, Q_A3T, lane);
+    o.t1 = quad(img, Q_A3T + 1, lane);
+}
+DEV void load_ops(BotOps &o, const float *img, int lane) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) b1[t] = quad(img, Q_B1 + t, lane);
-    f32x4 z0 = quad(img, Q_B2, lane), z1 = quad(img, Q_B2 + 1, lane);
-    f32x4 w0 = quad(img, Q_A2, lane), w1 = quad(img, Q_A2 + 4, lane);
-    FENCE();
+    for (int t = 0; t < 4; ++t) o.w[t] = quad(img, Q_A2T + 2 * t, lane);
+}
+DEV void load_ops(InOps &o, const float *img, int lane) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(a1[t], in, b1[t]);
+    for (int t = 0; t < 4; ++t) {
+        o.w0[t] = quad(img, Q_W1C + t, lane);
+        o.w1[t] = quad(img, Q_W1C + 4 + t, lane);
+    }
+}
+
+// z0, z1 += W2 (rows 0..15 | 16..31) x src, src = 64 values per sample in four quads.  ACT: src holds FC1
+// pre-activations without bias; bias and LeakyReLU are applied on the way in (b1 is read behind the FC1
+// MFMAs).  pre() runs before the last group.
+template <bool ACT, class Pre>
+DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, const f32x4 (&b1)[4], const float *img, int lane,
+                   float slope, Pre pre) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f32x4 n0 = w0, n1 = w1;
         if (t < 3) {
             n0 = quad(img, Q_A2 + t + 1, lane);
             n1 = quad(img, Q_A2 + 4 + t + 1, lane);
+        } else {
+            pre();
         }
         FENCE();
-        a.h1[t] = lrelu4(a.h1[t], slope);
+        if (ACT) src[t] = lrelu4(src[t] + b1[t], slope);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            z0 = mfma4(w0[r], a.h1[t][r], z0);
-            z1 = mfma4(w1[r], a.h1[t][r], z1);
+            z0 = mfma4(w0[r], src[t][r], z0);
+            z1 = mfma4(w1[r], src[t][r], z1);
         }
         FENCE();
         w0 = n0;
         w1 = n1;
     }
-#undef FENCE
+}
+
+// forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).
+template <class Pre>
+DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope, const FrontOps &o, Pre pre) {
+    f32x4 b1[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) b1[t] = quad(img, Q_B1 + t, lane);
+    FENCE();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, f32x4{0.f, 0.f, 0.f, 0.f});
+    f32x4 z0 = o.b2[0], z1 = o.b2[1];
+    fc2_block<true>(z0, z1, a.h1, o.w0, o.w1, b1, img, lane, slope, pre);
     a.h2[0] = lrelu4(z0, slope);
     a.h2[1] = lrelu4(z1, slope);
 }
-DEV void forward_back(Acts &a, const float *img, int lane, float slope) {
-    f32x4 y0 = quad(img, Q_B3, lane), y1 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4 w30 = quad(img, Q_A3, lane), w31 = quad(img, Q_A3 + 1, lane);
+// FC3 and the last layer (16 -> 1), which runs on the VALU: four FMAs per lane and a sum over the lane groups
+template <class Pre>
+DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc3Ops &o, Pre pre) {
+    pre();
+    FENCE();
+    f32x4 y0 = o.b3, y1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        y0 = mfma4(w30[r], a.h2[0][r], y0);
-        y1 = mfma4(w31[r], a.h2[1][r], y1);
+        y0 = mfma4(o.w30[r], a.h2[0][r], y0);
+        y1 = mfma4(o.w31[r], a.h2[1][r], y1);
     }
+    FENCE();
     a.h3 = lrelu4(y0 + y1, slope);
-    const f32x4 w4 = quad(img, Q_W4, lane);
-    float s = w4[0] * a.h3[0];
+    float s = o.w4[0] * a.h3[0];
 #pragma unroll
-    for (int r = 1; r < 4; ++r) s = __builtin_fmaf(w4[r], a.h3[r], s);
+    for (int r = 1; r < 4; ++r) s = __builtin_fmaf(o.w4[r], a.h3[r], s);
     a.score = sum_over_groups(s) + img[(Q_B4 * 64 + lane) * 4];
-}
-DEV void tile_forward(Acts &a, const float *img, int lane, float in, float slope) {
-    forward_front(a, img, lane, in, slope);
-    forward_back(a, img, lane, slope);
 }
 
 // back-propagation of an upstream vector through the three hidden layers, in two steps:
 //   top[r] (16 values on neurons 4g + r of layer 3, already masked) -> d2[2] (layer 2, masked) -> d1[4] (layer 1, masked)
-DEV void chain_top(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2]) {
-    const f32x4 t0 = quad(img, Q_A3T, lane), t1 = quad(img, Q_A3T + 1, lane);
+template <class Pre>
+DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps &o, Pre pre) {
+    pre();
+    FENCE();
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        e0 = mfma4(t0[r], top[r], e0);
-        e1 = mfma4(t1[r], top[r], e1);
+        e0 = mfma4(o.t0[r], top[r], e0);
+        e1 = mfma4(o.t1[r], top[r], e1);
     }
+    FENCE();
     d2[0] = e0 * m2[0];
     d2[1] = e1 * m2[1];
 }
-DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f32x4 (&m1)[4], f32x4 (&d1)[4]) {
-    f32x4 f[4];
+// pre() runs before the second half
+template <class Pre>
+DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f32x4 (&m1)[4], f32x4 (&d1)[4], const BotOps &o,
+                      Pre pre) {
+    f32x4 f[4], w2[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) f[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-        f32x4 w[4];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) w[t] = quad(img, Q_A2T + 2 * t + u, lane);
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-            for (int t = 0; t < 4; ++t) f[t] = mfma4(w[t][r], d2[u][r], f[t]);
+    for (int t = 0; t < 4; ++t) {
+        f[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        w2[t] = quad(img, Q_A2T + 2 * t + 1, lane);
     }
+    FENCE();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = mfma4(o.w[t][r], d2[0][r], f[t]);
+    FENCE();
+    pre();
+    FENCE();
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) f[t] = mfma4(w2[t][r], d2[1][r], f[t]);
+    FENCE();
 #pragma unroll
     for (int t = 0; t < 4; ++t) d1[t] = f[t] * m1[t];
-}
-DEV void chain_down(const float *img, int lane, f32x4 top, const f32x4 (&m2)[2], const f32x4 (&m1)[4], f32x4 (&d2)[2],
-                    f32x4 (&d1)[4]) {
-    chain_top(img, lane, top, m2, d2);
-    chain_bottom(img, lane, d2, m1, d1);
 }
 
 // (W1[:, 0:2])^T d1 -> the two input-gradient components, in every lane of sample j.  Two of sixteen
 // rows of an MFMA tile would be used, so this runs on the VALU: 32 FMAs per lane over its 16 neurons,
 // then the sum over the four lane groups for both components with three row swaps.
-DEV void to_input(const float *img, int lane, const f32x4 (&d1)[4], float &g0, float &g1) {
+DEV void to_input(const f32x4 (&d1)[4], float &g0, float &g1, const InOps &o) {
     float p0 = 0.f, p1 = 0.f;
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        const f32x4 w0 = quad(img, Q_W1C + t, lane), w1 = quad(img, Q_W1C + 4 + t, lane);
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            p0 = __builtin_fmaf(w0[r], d1[t][r], p0);
-            p1 = __builtin_fmaf(w1[r], d1[t][r], p1);
+            p0 = __builtin_fmaf(o.w0[t][r], d1[t][r], p0);
+            p1 = __builtin_fmaf(o.w1[t][r], d1[t][r], p1);
         }
-    }
     // halves: lanes 0..31 collect component 0 (rows g and g + 2), lanes 32..63 component 1
     const auto h = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1), false, false);
     unsigned x = h[0], y = h[1];
@@ -285,16 +347,26 @@ DEV void park_p1(char *wb, const Addr &ad, const f32x4 (&left)[4]) {
 }
 // One 4x4-block MFMA per sample: lane n = 4b + c multiplies left64[s][n] with columns 0..3 of sample s of the
 // constant region, so every product is a wanted one (a 16x16x4 tile would spend 16 columns on these 4).
-DEV void run_p1(Accum &ac, char *wb, const Addr &ad) {
+// Every run_* comes in two parts, read_* (LDS -> registers) and mfma_*, so that the caller can issue the
+// reads one MFMA group ahead.
+struct P1R {
+    float l[16], r[16];
+};
+DEV void read_p1(P1R &o, const char *wb, const Addr &ad) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        const float l = LD1(wb, ad.row64[(s >> 1) & 3] + 4 * s * P64);
-        const float r = LD1(wb, ad.col4 + 4 * (s * P16 + swz(s)));
-        if (s & 1) ac.p1b = mfma_blocks(r, l, ac.p1b);
-        else ac.p1 = mfma_blocks(r, l, ac.p1);
-        ac.p1_sum += l;
+        o.l[s] = LD1(wb, ad.row64[(s >> 1) & 3] + 4 * s * P64);
+        o.r[s] = LD1(wb, ad.col4 + 4 * (s * P16 + swz(s)));
     }
     __builtin_amdgcn_wave_barrier();
+}
+DEV void mfma_p1(Accum &ac, const P1R &o) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        if (s & 1) ac.p1b = mfma_blocks(o.r[s], o.l[s], ac.p1b);
+        else ac.p1 = mfma_blocks(o.r[s], o.l[s], ac.p1);
+        ac.p1_sum += o.l[s];
+    }
 }
 DEV void park_p2(char *wb, const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
 #pragma unroll
@@ -303,18 +375,27 @@ DEV void park_p2(char *wb, const Addr &ad, const f32x4 (&left)[4], const f32x4 (
     ST4(wb, ad.wr32 + 64, right[1]);
     __builtin_amdgcn_wave_barrier();
 }
-DEV void run_p2(Accum &ac, char *wb, const Addr &ad) {
+struct P2R {
+    float r0[4], r1[4], l[4][4];
+};
+DEV void read_p2(P2R &o, const char *wb, const Addr &ad) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float r0 = LD1(wb, ad.rr32[q]), r1 = LD1(wb, ad.rr32[q] + 64);
+        o.r0[q] = LD1(wb, ad.rr32[q]);
+        o.r1[q] = LD1(wb, ad.rr32[q] + 64);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const float l = LD1(wb, ad.rl64[q] + 64 * t);
-            ac.p2[t][0] = mfma4(l, r0, ac.p2[t][0]);
-            ac.p2[t][1] = mfma4(l, r1, ac.p2[t][1]);
-        }
+        for (int t = 0; t < 4; ++t) o.l[q][t] = LD1(wb, ad.rl64[q] + 64 * t);
     }
     __builtin_amdgcn_wave_barrier();
+}
+DEV void mfma_p2(Accum &ac, const P2R &o) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            ac.p2[t][0] = mfma4(o.l[q][t], o.r0[q], ac.p2[t][0]);
+            ac.p2[t][1] = mfma4(o.l[q][t], o.r1[q], ac.p2[t][1]);
+        }
 }
 DEV void park_p3(char *wb, const Addr &ad, const f32x4 (&left)[2], f32x4 right) {
     ST4(wb, ad.wl32, left[0]);
@@ -322,14 +403,24 @@ DEV void park_p3(char *wb, const Addr &ad, const f32x4 (&left)[2], f32x4 right) 
     ST4(wb, ad.wr16, right);
     __builtin_amdgcn_wave_barrier();
 }
-DEV void run_p3(Accum &ac, char *wb, const Addr &ad) {
+struct P3R {
+    float r[4], l0[4], l1[4];
+};
+DEV void read_p3(P3R &o, const char *wb, const Addr &ad) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const float r = LD1(wb, ad.rr16[q]);
-        ac.p3[0] = mfma4(LD1(wb, ad.rl32[q]), r, ac.p3[0]);
-        ac.p3[1] = mfma4(LD1(wb, ad.rl32[q] + 64), r, ac.p3[1]);
+        o.r[q] = LD1(wb, ad.rr16[q]);
+        o.l0[q] = LD1(wb, ad.rl32[q]);
+        o.l1[q] = LD1(wb, ad.rl32[q] + 64);
     }
     __builtin_amdgcn_wave_barrier();
+}
+DEV void mfma_p3(Accum &ac, const P3R &o) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        ac.p3[0] = mfma4(o.l0[q], o.r[q], ac.p3[0]);
+        ac.p3[1] = mfma4(o.l1[q], o.r[q], ac.p3[1]);
+    }
 }
 
 DEV void zero_accum(Accum &ac) {
@@ -461,13 +552,17 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__r
         return (tile < ntiles && n < N) ? (g < 2 ? x[2 * n + g] : cond[2 * n + g - 2]) : 0.f;
     };
     float in_next = fetch((int64_t)blockIdx.x * WAVES + wave);
+    FrontOps front;
+    load_ops(front, lds, lane);
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
         const int64_t n = tile * 16 + j;
         const bool valid = n < N;
         const float in = in_next;
         in_next = fetch(tile + stride);
         Acts a;
-        tile_forward(a, lds, lane, in, slope);
+        Fc3Ops o3;
+        forward_front(a, lds, lane, in, slope, front, [&] { load_ops(o3, lds, lane); });
+        forward_back(a, lds, lane, slope, o3, [&] { load_ops(front, lds, lane); });
         if (valid && g == 0) {
             if (score) score[n] = a.score;
             acc += a.score;
@@ -533,6 +628,8 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
         const int64_t n = tile * 16 + j;
         return (tile < ntiles && n < N) ? (gscore ? gscore[n] : gconst) : 0.f;
     };
+    FrontOps front;
+    load_ops(front, lds, lane);
     TileQueue tq;
     constexpr int NW = WGRAD ? WG_WAVES : WAVES;
     tq.init(queue, blockIdx.x * NW + wave, gridDim.x * NW);
@@ -553,9 +650,19 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
 #else
 #define STAMP(k)
 #endif
-        forward_front(a, lds, lane, in, slope);
-        if (WGRAD) run_p1(ac, wbuf, ad);     // previous tile: parked a whole forward ago, no LDS latency left
-        forward_back(a, lds, lane, slope);
+        Fc3Ops o3;
+        TopOps top;
+        BotOps bot;
+        InOps ino;
+        P1R p1r;
+        P2R p2r;
+        P3R p3r;
+        forward_front(a, lds, lane, in, slope, front, [&] {
+            load_ops(o3, lds, lane);
+            if (WGRAD) read_p1(p1r, wbuf, ad);   // previous tile's W1 gradient: parked a whole forward ago
+        });
+        if (WGRAD) mfma_p1(ac, p1r);
+        forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
         STAMP(1)
         ssum += (valid && g == 0) ? a.score : 0.f;
         f32x4 m1[4], m2[2];
@@ -569,20 +676,28 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
         // of the chain, whose MFMAs cover the LDS round trip: p3 (h2 x gz3) around the top of the chain,
         // p2 (h1 x gz2) around its bottom; only p1 (gz1 x input) follows its own park directly.
         if (WGRAD) park_p3(wbuf, ad, a.h2, gz3);
-        chain_top(lds, lane, gz3, m2, gz2);
+        chain_top(gz3, m2, gz2, top, [&] {
+            load_ops(bot, lds, lane);
+            if (WGRAD) read_p3(p3r, wbuf, ad);
+        });
         if (WGRAD) {
-            run_p3(ac, wbuf, ad);
+            mfma_p3(ac, p3r);
             park_p2(wbuf, ad, a.h1, gz2);
         }
-        chain_bottom(lds, lane, gz2, m1, gz1);
+        chain_bottom(lds, lane, gz2, m1, gz1, bot, [&] {
+            if (WGRAD) read_p2(p2r, wbuf, ad);
+            if (DX) load_ops(ino, lds, lane);
+        });
         STAMP(2)
+        load_ops(front, lds, lane);          // next tile
+        FENCE();
         if (WGRAD) {
-            run_p2(ac, wbuf, ad);
+            mfma_p2(ac, p2r);
             STAMP(4)
         }
         if (DX) {
             float g0, g1;
-            to_input(lds, lane, gz1, g0, g1);
+            to_input(gz1, g0, g1, ino);
             if (valid && g == 0) gx[n] = make_float2(g0, g1);
         }
         if (WGRAD) {
@@ -597,7 +712,11 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
             STAMP(3)
         }
     }
-    if (WGRAD) run_p1(ac, wbuf, ad);
+    if (WGRAD) {
+        P1R p1r;
+        read_p1(p1r, wbuf, ad);
+        mfma_p1(ac, p1r);
+    }
 #ifdef ABL_TIMING
     if (WGRAD && lane == 0)
         for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + k, tacc[k]);
@@ -667,6 +786,8 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         }
         return in;
     };
+    FrontOps front;
+    load_ops(front, lds, lane);
     TileQueue tq;
     tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES);
     int64_t tile_next = tq.tile();
@@ -680,7 +801,12 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         tile_next = tq.tile();
         in_next = fetch(tile_next);
         Acts a;
-        tile_forward(a, lds, lane, in, slope);
+        Fc3Ops o3;
+        TopOps top;
+        BotOps bot;
+        InOps ino;
+        forward_front(a, lds, lane, in, slope, front, [&] { load_ops(o3, lds, lane); });
+        forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
         f32x4 m1[4], m2[2];
         unsigned bits = 0u;
 #pragma unroll
@@ -699,9 +825,12 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         for (int r = 0; r < 4; ++r) bits |= (a.h3[r] > 0.f ? 1u : 0u) << (24 + r);
         const f32x4 v3 = w4 * mask4(a.h3, slope);
         f32x4 v2[2], v1[4];
-        chain_down(lds, lane, v3, m2, m1, v2, v1);
+        chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); });
+        chain_bottom(lds, lane, v2, m1, v1, bot, [&] { load_ops(ino, lds, lane); });
+        load_ops(front, lds, lane);          // next tile
+        FENCE();
         float g0, g1;
-        to_input(lds, lane, v1, g0, g1);
+        to_input(v1, g0, g1, ino);
         if (!valid) { g0 = 0.f; g1 = 0.f; }
         maskw[tile * 64 + lane] = bits;
         if (valid && g == 0) gout[n] = make_float2(g0, g1);
@@ -764,7 +893,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
     }
     f32x4 dw4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 w4 = quad(lds, Q_W4, lane);
-    const f32x4 a1 = quad(lds, Q_A1, lane);
+    FrontOps front;
+    load_ops(front, lds, lane);
     const int64_t ntiles = (N + 15) >> 4;
     // the tile's mask word, input gradient and row coefficient are loaded one tile ahead
     unsigned bits_next = 0u;
@@ -809,42 +939,52 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         const float ghb = g == 0 ? gh0 : (g == 1 ? gh1 : 0.f);
         f32x4 du1[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) du1[t] = mfma4(a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f}) * m1[t];
+        for (int t = 0; t < 4; ++t) du1[t] = mfma4(front.a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f}) * m1[t];
         // dv2 = W2 du1, du2 = dv2 * D2
         f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            const f32x4 w0 = quad(lds, Q_A2 + t, lane), w1 = quad(lds, Q_A2 + 4 + t, lane);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                z0 = mfma4(w0[r], du1[t][r], z0);
-                z1 = mfma4(w1[r], du1[t][r], z1);
-            }
-        }
-        run_p1(ac, wbuf, ad);                 // previous tile's v1 x gh
+        Fc3Ops o3;
+        TopOps top;
+        BotOps bot;
+        P1R p1r;
+        P2R p2r;
+        P3R p3r;
+        fc2_block<false>(z0, z1, du1, front.w0, front.w1, m1, lds, lane, slope, [&] {
+            load_ops(o3, lds, lane);
+            read_p1(p1r, wbuf, ad);           // previous tile's v1 x gh
+        });
+        mfma_p1(ac, p1r);
         f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
         // every outer-product phase is parked as soon as its factors exist and run after the next block of
         // chain MFMAs (which covers the LDS round trip): p3 = du2 x v3, p2 = du1 x v2, p1 = v1 x gh
         park_p3(wbuf, ad, du2, v3);
         // dv3 = W3 du2 ; dW4 += dv3 * D3
         f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 w30 = quad(lds, Q_A3, lane), w31 = quad(lds, Q_A3 + 1, lane);
+        load_ops(top, lds, lane);
+        read_p3(p3r, wbuf, ad);
+        FENCE();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            y0 = mfma4(w30[r], du2[0][r], y0);
-            y1 = mfma4(w31[r], du2[1][r], y1);
+            y0 = mfma4(o3.w30[r], du2[0][r], y0);
+            y1 = mfma4(o3.w31[r], du2[1][r], y1);
         }
+        FENCE();
         dw4 += (y0 + y1) * m3;
-        run_p3(ac, wbuf, ad);
-        chain_top(lds, lane, v3, m2, v2);
+        mfma_p3(ac, p3r);
+        chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); });
         park_p2(wbuf, ad, du1, v2);
-        chain_bottom(lds, lane, v2, m1, v1);
-        run_p2(ac, wbuf, ad);
+        chain_bottom(lds, lane, v2, m1, v1, bot, [&] { read_p2(p2r, wbuf, ad); });
+        load_ops(front, lds, lane);           // next tile
+        FENCE();
+        mfma_p2(ac, p2r);
         // gh tile: column g (< 2) of row j
         if (g < 2) *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = ghb;
         park_p1(wbuf, ad, v1);
     }
-    run_p1(ac, wbuf, ad);
+    {
+        P1R p1r;
+        read_p1(p1r, wbuf, ad);
+        mfma_p1(ac, p1r);
+    }
     __syncthreads();
     float *row = lds + wave * C_SLAB;
     for (int e = lane; e <= C_NP; e += 64) row[e] = 0.f;    // bias gradients and W1[:, 2:4] get no contribution
