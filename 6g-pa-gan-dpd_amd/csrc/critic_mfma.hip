@@ -119,6 +119,16 @@ DEV float sum_over_groups(float v) {
 // earlier, so the LDS latency of a read is covered by the MFMAs of the group before it.  The fences keep
 // the compiler from sinking those reads down to their first use.
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
+// experiment hook: ts == NULL in every product build (the code folds away); a timing build passes an
+// array whose slot 15 holds the last stamp
+#define TS(k)                                                      \
+    if (ts) {                                                      \
+        FENCE();                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter(); \
+        ts[k] += now_ - ts[15];                                    \
+        ts[15] = now_;                                             \
+        FENCE();                                                   \
+    }
 struct NoPre {
     DEV void operator()() const {}
 };
@@ -171,7 +181,8 @@ DEV void load_ops(InOps &o, const float *img, int lane) {
 // MFMAs).  pre() runs before the last group.
 template <bool ACT, class Pre>
 DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, const f32x4 (&b1)[4], const float *img, int lane,
-                   float slope, Pre pre) {
+                   float slope, Pre pre, unsigned long long *ts = nullptr) {
+    if (ACT) src[0] = lrelu4(src[0] + b1[0], slope);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f32x4 n0 = w0, n1 = w1;
@@ -182,7 +193,8 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, co
             pre();
         }
         FENCE();
-        if (ACT) src[t] = lrelu4(src[t] + b1[t], slope);
+        // the activation of the next quad sits in the issue shadow of this group's MFMAs
+        if (ACT && t < 3) src[t + 1] = lrelu4(src[t + 1] + b1[t + 1], slope);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z0 = mfma4(w0[r], src[t][r], z0);
@@ -191,26 +203,33 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, co
         FENCE();
         w0 = n0;
         w1 = n1;
+        TS(2 + t)
     }
 }
 
 // forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).
 template <class Pre>
-DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope, const FrontOps &o, Pre pre) {
+DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope, const FrontOps &o, Pre pre,
+                       unsigned long long *ts = nullptr) {
+    TS(0)
     f32x4 b1[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) b1[t] = quad(img, Q_B1 + t, lane);
     FENCE();
 #pragma unroll
     for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, f32x4{0.f, 0.f, 0.f, 0.f});
+    TS(1)
     f32x4 z0 = o.b2[0], z1 = o.b2[1];
-    fc2_block<true>(z0, z1, a.h1, o.w0, o.w1, b1, img, lane, slope, pre);
+    fc2_block<true>(z0, z1, a.h1, o.w0, o.w1, b1, img, lane, slope, pre, ts);
     a.h2[0] = lrelu4(z0, slope);
     a.h2[1] = lrelu4(z1, slope);
+    TS(6)
 }
 // FC3 and the last layer (16 -> 1), which runs on the VALU: four FMAs per lane and a sum over the lane groups
 template <class Pre>
-DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc3Ops &o, Pre pre) {
+DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc3Ops &o, Pre pre,
+                      unsigned long long *ts = nullptr) {
+    TS(7)
     pre();
     FENCE();
     f32x4 y0 = o.b3, y1 = {0.f, 0.f, 0.f, 0.f};
@@ -220,11 +239,13 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
         y1 = mfma4(o.w31[r], a.h2[1][r], y1);
     }
     FENCE();
+    TS(8)
     a.h3 = lrelu4(y0 + y1, slope);
     float s = o.w4[0] * a.h3[0];
 #pragma unroll
     for (int r = 1; r < 4; ++r) s = __builtin_fmaf(o.w4[r], a.h3[r], s);
     a.score = sum_over_groups(s) + img[(Q_B4 * 64 + lane) * 4];
+    TS(9)
 }
 
 // back-propagation of an upstream vector through the three hidden layers, in two steps:
@@ -617,6 +638,7 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
 #endif
 #ifdef ABL_TIMING
     unsigned long long tacc[6] = {0}, tlast = clk0;
+    unsigned long long fts[16] = {0};
 #endif
     const int64_t ntiles = (N + 15) >> 4;
     // the tile's input (and upstream gradient) is loaded one tile ahead
@@ -657,12 +679,18 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
         P1R p1r;
         P2R p2r;
         P3R p3r;
+#ifdef ABL_TIMING
+        fts[15] = __builtin_readcyclecounter();
+        unsigned long long *const ftp = fts;
+#else
+        unsigned long long *const ftp = nullptr;
+#endif
         forward_front(a, lds, lane, in, slope, front, [&] {
             load_ops(o3, lds, lane);
             if (WGRAD) read_p1(p1r, wbuf, ad);   // previous tile's W1 gradient: parked a whole forward ago
-        });
+        }, ftp);
         if (WGRAD) mfma_p1(ac, p1r);
-        forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
+        forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); }, ftp);
         STAMP(1)
         ssum += (valid && g == 0) ? a.score : 0.f;
         f32x4 m1[4], m2[2];
@@ -720,6 +748,8 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
 #ifdef ABL_TIMING
     if (WGRAD && lane == 0)
         for (int k = 0; k < 6; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + k, tacc[k]);
+    if (WGRAD && lane == 0)
+        for (int k = 0; k < 10; ++k) atomicAdd(reinterpret_cast<unsigned long long *>(slab + (size_t)2048 * C_SLAB) + 10 + k, fts[k]);
 #endif
 #if defined(ABL_TIMING) || defined(ABL_CLOCK)
     if (WGRAD && lane == 0) {   // slots 6, 7: their ratio is the shader clock in units of 100 MHz
