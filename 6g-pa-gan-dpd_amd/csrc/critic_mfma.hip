@@ -80,7 +80,9 @@ DEV void build_image(float *img, const float *__restrict__ wb) {
 DEV f32x4 quad(const float *img, int q, int lane) { return reinterpret_cast<const f32x4 *>(img)[q * 64 + lane]; }
 
 struct Acts {
-    f32x4 h1[4], h2[2], h3;   // post-activation; the LeakyReLU mask is read off the sign
+    f32x4 h1[4], h2[2], h3;   // post-activation
+    f32x4 m1[4], m2[2], m3;   // LeakyReLU derivative (1 or slope), from the same comparison as the activation
+    unsigned bits;            // BITS: the comparisons as one word (h1: bits 0..15, h2: 16..23, h3: 24..27)
     float score;
 };
 
@@ -89,6 +91,17 @@ DEV f32x4 lrelu4(f32x4 z, float slope) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[r] = z[r] > 0.f ? z[r] : z[r] * slope;
     return h;
+}
+// activation and its derivative from one comparison per element: h = z * m is z itself or z * slope
+template <bool BITS>
+DEV void act4(f32x4 z, float slope, f32x4 &h, f32x4 &m, unsigned &bits, int k0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const bool pos = z[r] > 0.f;
+        m[r] = pos ? 1.f : slope;
+        if (BITS) bits |= pos ? (1u << (k0 + r)) : 0u;
+    }
+    h = z * m;
 }
 DEV f32x4 mask4(f32x4 h, float slope) {
     f32x4 m;
@@ -179,10 +192,10 @@ DEV void load_ops(InOps &o, const float *img, int lane) {
 // z0, z1 += W2 (rows 0..15 | 16..31) x src, src = 64 values per sample in four quads.  ACT: src holds FC1
 // pre-activations without bias; bias and LeakyReLU are applied on the way in (b1 is read behind the FC1
 // MFMAs).  pre() runs before the last group.
-template <bool ACT, class Pre>
-DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, const f32x4 (&b1)[4], const float *img, int lane,
-                   float slope, Pre pre, unsigned long long *ts = nullptr) {
-    if (ACT) src[0] = lrelu4(src[0] + b1[0], slope);
+template <bool ACT, bool BITS, class Pre>
+DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, const f32x4 (&b1)[4], f32x4 (&m)[4], unsigned &bits,
+                   const float *img, int lane, float slope, Pre pre, unsigned long long *ts = nullptr) {
+    if (ACT) act4<BITS>(src[0] + b1[0], slope, src[0], m[0], bits, 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f32x4 n0 = w0, n1 = w1;
@@ -194,7 +207,7 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, co
         }
         FENCE();
         // the activation of the next quad sits in the issue shadow of this group's MFMAs
-        if (ACT && t < 3) src[t + 1] = lrelu4(src[t + 1] + b1[t + 1], slope);
+        if (ACT && t < 3) act4<BITS>(src[t + 1] + b1[t + 1], slope, src[t + 1], m[t + 1], bits, 4 * (t + 1));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z0 = mfma4(w0[r], src[t][r], z0);
@@ -208,9 +221,10 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, co
 }
 
 // forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).
-template <class Pre>
+template <bool BITS = false, class Pre>
 DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope, const FrontOps &o, Pre pre,
                        unsigned long long *ts = nullptr) {
+    a.bits = 0u;
     TS(0)
     f32x4 b1[4];
 #pragma unroll
@@ -220,13 +234,13 @@ DEV void forward_front(Acts &a, const float *img, int lane, float in, float slop
     for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, f32x4{0.f, 0.f, 0.f, 0.f});
     TS(1)
     f32x4 z0 = o.b2[0], z1 = o.b2[1];
-    fc2_block<true>(z0, z1, a.h1, o.w0, o.w1, b1, img, lane, slope, pre, ts);
-    a.h2[0] = lrelu4(z0, slope);
-    a.h2[1] = lrelu4(z1, slope);
+    fc2_block<true, BITS>(z0, z1, a.h1, o.w0, o.w1, b1, a.m1, a.bits, img, lane, slope, pre, ts);
+    act4<BITS>(z0, slope, a.h2[0], a.m2[0], a.bits, 16);
+    act4<BITS>(z1, slope, a.h2[1], a.m2[1], a.bits, 20);
     TS(6)
 }
 // FC3 and the last layer (16 -> 1), which runs on the VALU: four FMAs per lane and a sum over the lane groups
-template <class Pre>
+template <bool BITS = false, class Pre>
 DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc3Ops &o, Pre pre,
                       unsigned long long *ts = nullptr) {
     TS(7)
@@ -240,7 +254,7 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
     }
     FENCE();
     TS(8)
-    a.h3 = lrelu4(y0 + y1, slope);
+    act4<BITS>(y0 + y1, slope, a.h3, a.m3, a.bits, 24);
     float s = o.w4[0] * a.h3[0];
 #pragma unroll
     for (int r = 1; r < 4; ++r) s = __builtin_fmaf(o.w4[r], a.h3[r], s);
@@ -327,30 +341,34 @@ struct Accum {
     f32x4 p3[2];       // [left32 tile u]            x right16
 };
 
+// LDS addresses of this lane inside its wave's transposition buffer, wave base included: every access is
+// one register plus an immediate offset (no address arithmetic in the tile loop)
 struct Addr {
-    int wl64, wl32, wr32, wr16;     // byte offsets of this lane's float4 stores (row j, columns 4g..)
-    int rl64[4], rl32[4], rr32[4], rr16[4];   // byte offsets of operand reads for k-step q (row 4q + g, column j)
-    int row64[4];                   // p1: word lane ^ 4k of a left64 row (k = swizzle class of the row)
-    int col4;                       // p1: column lane & 3 of the constant region
+    char *wl64, *wl32, *wr32, *wr16;     // this lane's float4 stores (row j, columns 4g..)
+    char *rl64[4], *rl32[4], *rr32[4], *rr16[4];   // operand reads for k-step q (row 4q + g, column j)
+    char *row64[4];                      // p1: word lane ^ 4k of a left64 row (k = swizzle class of the row)
+    char *col4;                          // p1: column lane & 3 of the constant region
+    char *cst;                           // this lane's word of the constant region: column g of row j
 };
 
-DEV void make_addr(Addr &ad, int j, int g) {
-    ad.wl64 = 4 * (LEFT_W + j * P64 + ((4 * g) ^ swz(j)));
-    ad.wl32 = 4 * (LEFT_W + j * P32 + ((4 * g) ^ swz(j)));
-    ad.wr32 = 4 * (RIGHT_W + j * P32 + ((4 * g) ^ swz(j)));
-    ad.wr16 = 4 * (RIGHT_W + j * P16 + ((4 * g) ^ swz(j)));
+DEV void make_addr(Addr &ad, char *wb, int j, int g) {
+    ad.wl64 = wb + 4 * (LEFT_W + j * P64 + ((4 * g) ^ swz(j)));
+    ad.wl32 = wb + 4 * (LEFT_W + j * P32 + ((4 * g) ^ swz(j)));
+    ad.wr32 = wb + 4 * (RIGHT_W + j * P32 + ((4 * g) ^ swz(j)));
+    ad.wr16 = wb + 4 * (RIGHT_W + j * P16 + ((4 * g) ^ swz(j)));
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const int s = 4 * q + g, c = j ^ swz(s);
-        ad.rl64[q] = 4 * (LEFT_W + s * P64 + c);
-        ad.rl32[q] = 4 * (LEFT_W + s * P32 + c);
-        ad.rr32[q] = 4 * (RIGHT_W + s * P32 + c);
-        ad.rr16[q] = 4 * (RIGHT_W + s * P16 + c);
+        ad.rl64[q] = wb + 4 * (LEFT_W + s * P64 + c);
+        ad.rl32[q] = wb + 4 * (LEFT_W + s * P32 + c);
+        ad.rr32[q] = wb + 4 * (RIGHT_W + s * P32 + c);
+        ad.rr16[q] = wb + 4 * (RIGHT_W + s * P16 + c);
     }
     const int lane = 16 * g + j;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) ad.row64[k] = 4 * (LEFT_W + (lane ^ (4 * k)));
-    ad.col4 = 4 * (CONST_W + (lane & 3));
+    for (int k = 0; k < 4; ++k) ad.row64[k] = wb + 4 * (LEFT_W + (lane ^ (4 * k)));
+    ad.col4 = wb + 4 * (CONST_W + (lane & 3));
+    ad.cst = wb + 4 * (CONST_W + j * P16 + (g ^ swz(j)));
 }
 
 #define ST4(base, off, v) (*reinterpret_cast<f32x4 *>((base) + (off)) = (v))
@@ -361,9 +379,9 @@ DEV void make_addr(Addr &ad, int j, int g) {
 // after the previous one has run; between a park and its run the caller places other MFMA work, which
 // covers the store -> read round trip through LDS (LDS operations of a wave execute in order).
 // p1 += left64^T (x) cst16 where the 16-column right tile lives in the wave's constant region
-DEV void park_p1(char *wb, const Addr &ad, const f32x4 (&left)[4]) {
+DEV void park_p1(const Addr &ad, const f32x4 (&left)[4]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ST4(wb, ad.wl64 + 64 * t, left[t]);
+    for (int t = 0; t < 4; ++t) ST4(ad.wl64, 64 * t, left[t]);
     __builtin_amdgcn_wave_barrier();
 }
 // One 4x4-block MFMA per sample: lane n = 4b + c multiplies left64[s][n] with columns 0..3 of sample s of the
@@ -373,11 +391,11 @@ DEV void park_p1(char *wb, const Addr &ad, const f32x4 (&left)[4]) {
 struct P1R {
     float l[16], r[16];
 };
-DEV void read_p1(P1R &o, const char *wb, const Addr &ad) {
+DEV void read_p1(P1R &o, const Addr &ad) {
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
-        o.l[s] = LD1(wb, ad.row64[(s >> 1) & 3] + 4 * s * P64);
-        o.r[s] = LD1(wb, ad.col4 + 4 * (s * P16 + swz(s)));
+        o.l[s] = LD1(ad.row64[(s >> 1) & 3], 4 * s * P64);
+        o.r[s] = LD1(ad.col4, 4 * (s * P16 + swz(s)));
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -389,23 +407,23 @@ DEV void mfma_p1(Accum &ac, const P1R &o) {
         ac.p1_sum += o.l[s];
     }
 }
-DEV void park_p2(char *wb, const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
+DEV void park_p2(const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) ST4(wb, ad.wl64 + 64 * t, left[t]);
-    ST4(wb, ad.wr32, right[0]);
-    ST4(wb, ad.wr32 + 64, right[1]);
+    for (int t = 0; t < 4; ++t) ST4(ad.wl64, 64 * t, left[t]);
+    ST4(ad.wr32, 0, right[0]);
+    ST4(ad.wr32, 64, right[1]);
     __builtin_amdgcn_wave_barrier();
 }
 struct P2R {
     float r0[4], r1[4], l[4][4];
 };
-DEV void read_p2(P2R &o, const char *wb, const Addr &ad) {
+DEV void read_p2(P2R &o, const Addr &ad) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        o.r0[q] = LD1(wb, ad.rr32[q]);
-        o.r1[q] = LD1(wb, ad.rr32[q] + 64);
+        o.r0[q] = LD1(ad.rr32[q], 0);
+        o.r1[q] = LD1(ad.rr32[q], 64);
 #pragma unroll
-        for (int t = 0; t < 4; ++t) o.l[q][t] = LD1(wb, ad.rl64[q] + 64 * t);
+        for (int t = 0; t < 4; ++t) o.l[q][t] = LD1(ad.rl64[q], 64 * t);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -418,21 +436,21 @@ DEV void mfma_p2(Accum &ac, const P2R &o) {
             ac.p2[t][1] = mfma4(o.l[q][t], o.r1[q], ac.p2[t][1]);
         }
 }
-DEV void park_p3(char *wb, const Addr &ad, const f32x4 (&left)[2], f32x4 right) {
-    ST4(wb, ad.wl32, left[0]);
-    ST4(wb, ad.wl32 + 64, left[1]);
-    ST4(wb, ad.wr16, right);
+DEV void park_p3(const Addr &ad, const f32x4 (&left)[2], f32x4 right) {
+    ST4(ad.wl32, 0, left[0]);
+    ST4(ad.wl32, 64, left[1]);
+    ST4(ad.wr16, 0, right);
     __builtin_amdgcn_wave_barrier();
 }
 struct P3R {
     float r[4], l0[4], l1[4];
 };
-DEV void read_p3(P3R &o, const char *wb, const Addr &ad) {
+DEV void read_p3(P3R &o, const Addr &ad) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        o.r[q] = LD1(wb, ad.rr16[q]);
-        o.l0[q] = LD1(wb, ad.rl32[q]);
-        o.l1[q] = LD1(wb, ad.rl32[q] + 64);
+        o.r[q] = LD1(ad.rr16[q], 0);
+        o.l0[q] = LD1(ad.rl32[q], 0);
+        o.l1[q] = LD1(ad.rl32[q], 64);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -621,7 +639,7 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
     f32x4 db2[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}}, db3 = {0.f, 0.f, 0.f, 0.f}, dw4 = {0.f, 0.f, 0.f, 0.f};
     float db4 = 0.f;
     if (WGRAD) {
-        make_addr(ad, j, g);
+        make_addr(ad, wbuf, j, g);
         zero_accum(ac);
         float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
         for (int k = lane; k < 256; k += 64) cst[k] = 0.f;            // the input tile [sample][in0..3]
@@ -687,33 +705,30 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
 #endif
         forward_front(a, lds, lane, in, slope, front, [&] {
             load_ops(o3, lds, lane);
-            if (WGRAD) read_p1(p1r, wbuf, ad);   // previous tile's W1 gradient: parked a whole forward ago
+            if (WGRAD) read_p1(p1r, ad);   // previous tile's W1 gradient: parked a whole forward ago
         }, ftp);
         if (WGRAD) mfma_p1(ac, p1r);
         forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); }, ftp);
         STAMP(1)
         ssum += (valid && g == 0) ? a.score : 0.f;
-        f32x4 m1[4], m2[2];
-#pragma unroll
-        for (int t = 0; t < 4; ++t) m1[t] = mask4(a.h1[t], slope);
-        m2[0] = mask4(a.h2[0], slope);
-        m2[1] = mask4(a.h2[1], slope);
-        const f32x4 gz3 = w4 * gs * mask4(a.h3, slope);
+        const f32x4 (&m1)[4] = a.m1;
+        const f32x4 (&m2)[2] = a.m2;
+        const f32x4 gz3 = w4 * gs * a.m3;
         f32x4 gz2[2], gz1[4];
         // The outer-product phases are parked as soon as their factors exist and run after the next piece
         // of the chain, whose MFMAs cover the LDS round trip: p3 (h2 x gz3) around the top of the chain,
         // p2 (h1 x gz2) around its bottom; only p1 (gz1 x input) follows its own park directly.
-        if (WGRAD) park_p3(wbuf, ad, a.h2, gz3);
+        if (WGRAD) park_p3(ad, a.h2, gz3);
         chain_top(gz3, m2, gz2, top, [&] {
             load_ops(bot, lds, lane);
-            if (WGRAD) read_p3(p3r, wbuf, ad);
+            if (WGRAD) read_p3(p3r, ad);
         });
         if (WGRAD) {
             mfma_p3(ac, p3r);
-            park_p2(wbuf, ad, a.h1, gz2);
+            park_p2(ad, a.h1, gz2);
         }
         chain_bottom(lds, lane, gz2, m1, gz1, bot, [&] {
-            if (WGRAD) read_p2(p2r, wbuf, ad);
+            if (WGRAD) read_p2(p2r, ad);
             if (DX) load_ops(ino, lds, lane);
         });
         STAMP(2)
@@ -735,14 +750,14 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
             dw4 += a.h3 * gs;
             db4 += gs;
             // the input tile: column g of row j
-            *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = in;
-            park_p1(wbuf, ad, gz1);
+            *reinterpret_cast<float *>(ad.cst) = in;
+            park_p1(ad, gz1);
             STAMP(3)
         }
     }
     if (WGRAD) {
         P1R p1r;
-        read_p1(p1r, wbuf, ad);
+        read_p1(p1r, ad);
         mfma_p1(ac, p1r);
     }
 #ifdef ABL_TIMING
@@ -835,25 +850,12 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         TopOps top;
         BotOps bot;
         InOps ino;
-        forward_front(a, lds, lane, in, slope, front, [&] { load_ops(o3, lds, lane); });
-        forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
-        f32x4 m1[4], m2[2];
-        unsigned bits = 0u;
-#pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            m1[t] = mask4(a.h1[t], slope);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bits |= (a.h1[t][r] > 0.f ? 1u : 0u) << (4 * t + r);
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            m2[u] = mask4(a.h2[u], slope);
-#pragma unroll
-            for (int r = 0; r < 4; ++r) bits |= (a.h2[u][r] > 0.f ? 1u : 0u) << (16 + 4 * u + r);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bits |= (a.h3[r] > 0.f ? 1u : 0u) << (24 + r);
-        const f32x4 v3 = w4 * mask4(a.h3, slope);
+        forward_front<true>(a, lds, lane, in, slope, front, [&] { load_ops(o3, lds, lane); });
+        forward_back<true>(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
+        const f32x4 (&m1)[4] = a.m1;
+        const f32x4 (&m2)[2] = a.m2;
+        const unsigned bits = a.bits;
+        const f32x4 v3 = w4 * a.m3;
         f32x4 v2[2], v1[4];
         chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); });
         chain_bottom(lds, lane, v2, m1, v1, bot, [&] { load_ops(ino, lds, lane); });
@@ -911,7 +913,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
     char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + wave * WAVE_WORDS);
     Addr ad;
     Accum ac;
-    make_addr(ad, j, g);
+    make_addr(ad, wbuf, j, g);
     zero_accum(ac);
     {
         float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
@@ -953,16 +955,24 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         tile = tq.tile();
         fetch(tile);
         f32x4 m1[4], m2[2], m3;
+        // two instructions per mask: the bit, sign-extended to a full word, selects between the bit
+        // patterns of 1.0 and of the slope
+        auto unpack = [&](int k) {
+            const int sel = __builtin_amdgcn_sbfe((int)bits, k, 1);
+            float m;   // (sel & 1.0) | (~sel & slope); the compiler does not form this instruction by itself
+            asm("v_bfi_b32 %0, %1, 1.0, %2" : "=v"(m) : "v"(sel), "s"(slope));
+            return m;
+        };
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m1[t][r] = ((bits >> (4 * t + r)) & 1u) ? 1.f : slope;
+            for (int r = 0; r < 4; ++r) m1[t][r] = unpack(4 * t + r);
 #pragma unroll
         for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) m2[u][r] = ((bits >> (16 + 4 * u + r)) & 1u) ? 1.f : slope;
+            for (int r = 0; r < 4; ++r) m2[u][r] = unpack(16 + 4 * u + r);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) m3[r] = ((bits >> (24 + r)) & 1u) ? 1.f : slope;
+        for (int r = 0; r < 4; ++r) m3[r] = unpack(24 + r);
         const f32x4 v3 = w4 * m3;
         f32x4 v2[2], v1[4];
         // du1 = (W1[:, 0:2] gh) * D1 : k = input column on the lane groups (groups 2, 3 carry zeros)
@@ -978,19 +988,20 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         P1R p1r;
         P2R p2r;
         P3R p3r;
-        fc2_block<false>(z0, z1, du1, front.w0, front.w1, m1, lds, lane, slope, [&] {
+        unsigned no_bits = 0u;
+        fc2_block<false, false>(z0, z1, du1, front.w0, front.w1, m1, m1, no_bits, lds, lane, slope, [&] {
             load_ops(o3, lds, lane);
-            read_p1(p1r, wbuf, ad);           // previous tile's v1 x gh
+            read_p1(p1r, ad);           // previous tile's v1 x gh
         });
         mfma_p1(ac, p1r);
         f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
         // every outer-product phase is parked as soon as its factors exist and run after the next block of
         // chain MFMAs (which covers the LDS round trip): p3 = du2 x v3, p2 = du1 x v2, p1 = v1 x gh
-        park_p3(wbuf, ad, du2, v3);
+        park_p3(ad, du2, v3);
         // dv3 = W3 du2 ; dW4 += dv3 * D3
         f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
         load_ops(top, lds, lane);
-        read_p3(p3r, wbuf, ad);
+        read_p3(p3r, ad);
         FENCE();
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1001,18 +1012,18 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         dw4 += (y0 + y1) * m3;
         mfma_p3(ac, p3r);
         chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); });
-        park_p2(wbuf, ad, du1, v2);
-        chain_bottom(lds, lane, v2, m1, v1, bot, [&] { read_p2(p2r, wbuf, ad); });
+        park_p2(ad, du1, v2);
+        chain_bottom(lds, lane, v2, m1, v1, bot, [&] { read_p2(p2r, ad); });
         load_ops(front, lds, lane);           // next tile
         FENCE();
         mfma_p2(ac, p2r);
         // gh tile: column g (< 2) of row j
-        if (g < 2) *reinterpret_cast<float *>(wbuf + 4 * (CONST_W + j * P16 + (g ^ swz(j)))) = ghb;
-        park_p1(wbuf, ad, v1);
+        if (g < 2) *reinterpret_cast<float *>(ad.cst) = ghb;
+        park_p1(ad, v1);
     }
     {
         P1R p1r;
-        read_p1(p1r, wbuf, ad);
+        read_p1(p1r, ad);
         mfma_p1(ac, p1r);
     }
     __syncthreads();
