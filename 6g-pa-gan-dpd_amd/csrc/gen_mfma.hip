@@ -147,15 +147,37 @@ DEV float tanh_f32(float x) {
 // the per-lane partial sums (this lane group's four h2 neurons) cost 16 FMAs for both tiles and the
 // sum over the four lane groups takes three row swaps.  Lane (g, j) ends up with z3[g & 1] of sample j
 // of tile g >> 1.  w3[k][r] = W3[k][4g + r]; b3k = b3[g & 1].
-DEV float fc3_pair(const float (&w3)[2][4], float b3k, const f32x4 &hA, const f32x4 &hB) {
-    float pa0 = w3[0][0] * hA[0], pa1 = w3[1][0] * hA[0], pb0 = w3[0][0] * hB[0], pb1 = w3[1][0] * hB[0];
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// quad arithmetic as two packed instructions (the compiler leaves about half of such quads as four scalar
+// instructions; every VALU instruction costs the fp32 MFMAs issue time)
+DEV f32x4 mul4(f32x4 a, f32x4 b) {
+#ifdef NO_PK_ASM
+    return a * b;
+#endif
+    f32x2 lo, hi;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+DEV f32x4 add4(f32x4 a, f32x4 b) {
+#ifdef NO_PK_ASM
+    return a + b;
+#endif
+    f32x2 lo, hi;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+// (the partial sums of the two outputs travel as a pair: packed multiplies and FMAs, half the VALU
+// instructions, which on this hardware take issue time away from the fp32 MFMAs one for one)
+DEV float fc3_pair(const f32x2 (&w3p)[4], float b3k, const f32x4 &hA, const f32x4 &hB) {
+    f32x2 pa = w3p[0] * f32x2{hA[0], hA[0]}, pb = w3p[0] * f32x2{hB[0], hB[0]};
 #pragma unroll
     for (int r = 1; r < 4; ++r) {
-        pa0 = __builtin_fmaf(w3[0][r], hA[r], pa0);
-        pa1 = __builtin_fmaf(w3[1][r], hA[r], pa1);
-        pb0 = __builtin_fmaf(w3[0][r], hB[r], pb0);
-        pb1 = __builtin_fmaf(w3[1][r], hB[r], pb1);
+        pa = __builtin_elementwise_fma(w3p[r], f32x2{hA[r], hA[r]}, pa);
+        pb = __builtin_elementwise_fma(w3p[r], f32x2{hB[r], hB[r]}, pb);
     }
+    const float pa0 = pa[0], pa1 = pa[1], pb0 = pb[0], pb1 = pb[1];
     // halves: lanes 0..31 collect tile A (rows g and g + 2), lanes 32..63 tile B
     const auto h0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa0), __builtin_bit_cast(unsigned, pb0), false, false);
     const auto h1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa1), __builtin_bit_cast(unsigned, pb1), false, false);
@@ -215,11 +237,9 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         int slot = 4 * s + g;
         boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
-    float w3v[2][4];  // W3[k][4g + r]: FC3 runs on the VALU
+    f32x2 w3p[4];     // (W3[0][4g + r], W3[1][4g + r]): FC3 runs on the VALU
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w3v[k][r] = wq[G_W3 + k * 16 + 4 * g + r];
+    for (int r = 0; r < 4; ++r) w3p[r] = f32x2{wq[G_W3 + 4 * g + r], wq[G_W3 + 16 + 4 * g + r]};
     const float b3k = wq[G_B3 + (g & 1)];
     QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
     if (QAT) {
@@ -321,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                 if (DEPTH >= 3) {
                     V2(B, vB);
                     // lane (g, j): output g & 1 of sample j of tile g >> 1
-                    float y = tanh_f32(fc3_pair(w3v, b3k, A.h2, B.h2));
+                    float y = tanh_f32(fc3_pair(w3p, b3k, A.h2, B.h2));
                     const int64_t t = t0_cur + 32 * p + 16 * (g >> 1) + j;
                     if (QAT && !PA) amax = fmaxf(amax, t < L ? fabsf(y) : 0.f);
                     if (QAT && PA) y = fq16(y, s3);
@@ -409,11 +429,14 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) A2T[t][r] = wq[G_W2 + (4 * g + r) * 32 + 16 * t + j];
-    float w3v[2][4];  // W3[k][4g + r]: FC3 and its input gradient run on the VALU
+    f32x2 w3p[4];     // (W3[0][4g + r], W3[1][4g + r]): FC3 and its input gradient run on the VALU
+    f32x4 w3r[2];     // the same weights by row, for the input gradient
 #pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) w3v[k][r] = wq[G_W3 + k * 16 + 4 * g + r];
+    for (int r = 0; r < 4; ++r) {
+        w3p[r] = f32x2{wq[G_W3 + 4 * g + r], wq[G_W3 + 16 + 4 * g + r]};
+        w3r[0][r] = w3p[r][0];
+        w3r[1][r] = w3p[r][1];
+    }
     const float b3k = wq[G_B3 + (g & 1)];
     int boff[8];
 #pragma unroll
@@ -452,7 +475,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #pragma unroll
         for (int t = 0; t < 2; ++t) dW1[u][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float dW3[2][4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    f32x4 dW3[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
     f32x4 db2 = {0.f, 0.f, 0.f, 0.f};
     float db3 = 0.f;
     float loss = 0.f;
@@ -488,8 +511,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             t.m1a[r] = t.a0[r] > 0.f ? 1.f : slope;
             t.m1b[r] = t.a1[r] > 0.f ? 1.f : slope;
         }
-        t.a0 *= t.m1a;
-        t.a1 *= t.m1b;
+        t.a0 = mul4(t.a0, t.m1a);
+        t.a1 = mul4(t.a1, t.m1b);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             t.ha[r] = QAT ? fq16(t.a0[r], s1) : t.a0[r];
@@ -509,10 +532,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         }
     };
     auto V2 = [&](Tile &t) {
-        t.c0 += t.c1;
+        t.c0 = add4(t.c0, t.c1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) t.m2[r] = t.c0[r] > 0.f ? 1.f : slope;
-        t.c0 *= t.m2;
+        t.c0 = mul4(t.c0, t.m2);
 #pragma unroll
         for (int r = 0; r < 4; ++r) t.h2[r] = QAT ? fq16(t.c0[r], s2) : t.c0[r];
     };
@@ -522,7 +545,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // neuron) follow on the VALU.
     const int tg_off = 2 * (16 * (g >> 1) + j) + (g & 1);
     auto V3P = [&](Tile &A, Tile &B, int p, int64_t t0_cur) {
-        const float y = tanh_f32(fc3_pair(w3v, b3k, A.h2, B.h2));
+        const float y = tanh_f32(fc3_pair(w3p, b3k, A.h2, B.h2));
         const bool valid = (t0_cur + 32 * p + 16 * (g >> 1) + j) < L;
         const float v = tg_f[tg_off + 64 * p];
         float gup;
@@ -547,20 +570,16 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         asm volatile("" : "+v"(ua0), "+v"(ub0), "+v"(ua1), "+v"(ub1));
         const float a0 = __builtin_bit_cast(float, ua0), b0 = __builtin_bit_cast(float, ub0);
         const float a1 = __builtin_bit_cast(float, ua1), b1 = __builtin_bit_cast(float, ub1);
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            dW3[0][r4] = __builtin_fmaf(a0, A.h2[r4], dW3[0][r4]);
-            dW3[1][r4] = __builtin_fmaf(a1, A.h2[r4], dW3[1][r4]);
-            dW3[0][r4] = __builtin_fmaf(b0, B.h2[r4], dW3[0][r4]);
-            dW3[1][r4] = __builtin_fmaf(b1, B.h2[r4], dW3[1][r4]);
-        }
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-            A.gz2[r4] = __builtin_fmaf(w3v[1][r4], a1, w3v[0][r4] * a0) * A.m2[r4];
-            B.gz2[r4] = __builtin_fmaf(w3v[1][r4], b1, w3v[0][r4] * b0) * B.m2[r4];
-        }
-        db2 += A.gz2;
-        db2 += B.gz2;
+        // whole quads at a time: the compiler turns these into packed multiplies and FMAs
+        const f32x4 a0v = {a0, a0, a0, a0}, a1v = {a1, a1, a1, a1}, b0v = {b0, b0, b0, b0}, b1v = {b1, b1, b1, b1};
+        dW3[0] = __builtin_elementwise_fma(a0v, A.h2, dW3[0]);
+        dW3[1] = __builtin_elementwise_fma(a1v, A.h2, dW3[1]);
+        dW3[0] = __builtin_elementwise_fma(b0v, B.h2, dW3[0]);
+        dW3[1] = __builtin_elementwise_fma(b1v, B.h2, dW3[1]);
+        A.gz2 = mul4(__builtin_elementwise_fma(w3r[1], a1v, mul4(w3r[0], a0v)), A.m2);
+        B.gz2 = mul4(__builtin_elementwise_fma(w3r[1], b1v, mul4(w3r[0], b0v)), B.m2);
+        db2 = add4(db2, A.gz2);
+        db2 = add4(db2, B.gz2);
     };
     auto V4 = [&](Tile &t, int buf) {
         *reinterpret_cast<f32x4 *>(ser_b + 4 * (GZ_W + TILE_W * buf) + wr32 + 128) = t.gz2;
@@ -575,8 +594,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         }
     };
     auto V5 = [&](Tile &t, int buf) {
-        t.e0 *= t.m1a;
-        t.e1 *= t.m1b;
+        t.e0 = mul4(t.e0, t.m1a);
+        t.e1 = mul4(t.e1, t.m1b);
         char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
         *reinterpret_cast<f32x4 *>(gz_b + wr32) = t.e0;
         *reinterpret_cast<f32x4 *>(gz_b + wr32 + 64) = t.e1;
