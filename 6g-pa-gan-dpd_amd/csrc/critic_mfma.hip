@@ -17,6 +17,7 @@ int gen_reduce_slab_generic(const float *slab, int n_partials, int row_len, int 
 
 namespace {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 // sixteen independent 4x4 outer products: lane 4b + i of `a` times lane 4b + j of `b` -> register i of lane 4b + j
@@ -145,8 +146,8 @@ DEV float sum_over_groups(float v) {
 struct NoPre {
     DEV void operator()() const {}
 };
-struct FrontOps {      // FC1 weights, FC2 accumulator start (b2) and the first FC2 weight pair
-    f32x4 a1, b2[2], w0, w1;
+struct FrontOps {      // FC1 weights and accumulator start (b1), FC2 accumulator start (b2), first FC2 weight pair
+    f32x4 a1, b1[4], b2[2], w0, w1;
 };
 struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 for the VALU last layer
     f32x4 b3, w30, w31, w4;
@@ -162,6 +163,8 @@ struct InOps {         // W1[:, 0:2] per neuron, VALU operands
 };
 DEV void load_ops(FrontOps &o, const float *img, int lane) {
     o.a1 = quad(img, Q_A1, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o.b1[t] = quad(img, Q_B1 + t, lane);
     o.b2[0] = quad(img, Q_B2, lane);
     o.b2[1] = quad(img, Q_B2 + 1, lane);
     o.w0 = quad(img, Q_A2, lane);
@@ -190,12 +193,11 @@ DEV void load_ops(InOps &o, const float *img, int lane) {
 }
 
 // z0, z1 += W2 (rows 0..15 | 16..31) x src, src = 64 values per sample in four quads.  ACT: src holds FC1
-// pre-activations without bias; bias and LeakyReLU are applied on the way in (b1 is read behind the FC1
-// MFMAs).  pre() runs before the last group.
+// pre-activations; LeakyReLU is applied on the way in.  pre() runs before the last group.
 template <bool ACT, bool BITS, class Pre>
-DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, const f32x4 (&b1)[4], f32x4 (&m)[4], unsigned &bits,
+DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, f32x4 (&m)[4], unsigned &bits,
                    const float *img, int lane, float slope, Pre pre, unsigned long long *ts = nullptr) {
-    if (ACT) act4<BITS>(src[0] + b1[0], slope, src[0], m[0], bits, 0);
+    if (ACT) act4<BITS>(src[0], slope, src[0], m[0], bits, 0);
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f32x4 n0 = w0, n1 = w1;
@@ -207,7 +209,7 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], f32x4 w0, f32x4 w1, co
         }
         FENCE();
         // the activation of the next quad sits in the issue shadow of this group's MFMAs
-        if (ACT && t < 3) act4<BITS>(src[t + 1] + b1[t + 1], slope, src[t + 1], m[t + 1], bits, 4 * (t + 1));
+        if (ACT && t < 3) act4<BITS>(src[t + 1], slope, src[t + 1], m[t + 1], bits, 4 * (t + 1));
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             z0 = mfma4(w0[r], src[t][r], z0);
@@ -226,15 +228,11 @@ DEV void forward_front(Acts &a, const float *img, int lane, float in, float slop
                        unsigned long long *ts = nullptr) {
     a.bits = 0u;
     TS(0)
-    f32x4 b1[4];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) b1[t] = quad(img, Q_B1 + t, lane);
-    FENCE();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, f32x4{0.f, 0.f, 0.f, 0.f});
+    for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, o.b1[t]);
     TS(1)
     f32x4 z0 = o.b2[0], z1 = o.b2[1];
-    fc2_block<true, BITS>(z0, z1, a.h1, o.w0, o.w1, b1, a.m1, a.bits, img, lane, slope, pre, ts);
+    fc2_block<true, BITS>(z0, z1, a.h1, o.w0, o.w1, a.m1, a.bits, img, lane, slope, pre, ts);
     act4<BITS>(z0, slope, a.h2[0], a.m2[0], a.bits, 16);
     act4<BITS>(z1, slope, a.h2[1], a.m2[1], a.bits, 20);
     TS(6)
@@ -336,7 +334,7 @@ DEV void to_input(const f32x4 (&d1)[4], float &g0, float &g1, const InOps &o) {
 // ---- outer-product accumulation over the 16 samples of a tile --------------------------------------
 struct Accum {
     f32x4 p1, p1b;     // lane n: sum over (even, odd) samples of left64[n] * (columns 0..3 of the right tile)
-    float p1_sum;      // lane n: sum over samples of left64[n]
+    f32x2 p1_sum;      // lane n: sum over (even, odd) samples of left64[n]
     f32x4 p2[4][2];    // [left64 tile t][right32 u]
     f32x4 p3[2];       // [left32 tile u]            x right16
 };
@@ -404,7 +402,7 @@ DEV void mfma_p1(Accum &ac, const P1R &o) {
     for (int s = 0; s < 16; ++s) {
         if (s & 1) ac.p1b = mfma_blocks(o.r[s], o.l[s], ac.p1b);
         else ac.p1 = mfma_blocks(o.r[s], o.l[s], ac.p1);
-        ac.p1_sum += o.l[s];
+        if (s & 1) ac.p1_sum += f32x2{o.l[s - 1], o.l[s]};
     }
 }
 DEV void park_p2(const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
@@ -466,7 +464,7 @@ DEV void zero_accum(Accum &ac) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
     ac.p1 = z;
     ac.p1b = z;
-    ac.p1_sum = 0.f;
+    ac.p1_sum = f32x2{0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         ac.p2[t][0] = z;
@@ -485,7 +483,7 @@ DEV void store_row(float *row, const Accum &ac, int j, int g, int ncol1, bool bi
 #pragma unroll
         for (int c = 0; c < 4; ++c)
             if (c < ncol1) row[C_W1 + n * 4 + c] = ac.p1[c] + ac.p1b[c];
-        if (bias1) row[C_B1 + n] = ac.p1_sum;
+        if (bias1) row[C_B1 + n] = ac.p1_sum[0] + ac.p1_sum[1];
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t)
@@ -989,7 +987,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         P2R p2r;
         P3R p3r;
         unsigned no_bits = 0u;
-        fc2_block<false, false>(z0, z1, du1, front.w0, front.w1, m1, m1, no_bits, lds, lane, slope, [&] {
+        fc2_block<false, false>(z0, z1, du1, front.w0, front.w1, m1, no_bits, lds, lane, slope, [&] {
             load_ops(o3, lds, lane);
             read_p1(p1r, ad);           // previous tile's v1 x gh
         });
