@@ -1,6 +1,6 @@
 """Launch the fused Stage-1 kernel a few times (for counter collection)."""
-import sys, torch
-sys.path.insert(0, '.')
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import dpd_amd
 from dpd_amd import _lib as L
 from dpd_amd.data import ofdm_rows
