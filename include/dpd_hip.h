@@ -55,7 +55,7 @@ int dpd_version(void);
  * makes its gradients bitwise reproducible from run to run (default 0: chunks are handed out first
  * come, first served, ~3 % faster, gradients reproducible to fp32 summation order).
  * "critic_deterministic": the same choice for the MFMA critic backward and gradient-penalty kernels
- * (default 0: tiles first come, first served, ~10 % faster; 1: fixed order, bitwise reproducible). */
+ * (default 0: tiles first come, first served, ~4 % faster; 1: fixed order, bitwise reproducible). */
 int dpd_set_option(const char *name, int value);
 
 /* Scratch size in bytes for the ws-taking entry points: dpd_workspace_bytes(0) suffices for every
