@@ -677,23 +677,34 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     const unsigned n_waves = gridDim.x * WAVES, cpr32 = (unsigned)cpr, n_chunks32 = (unsigned)n_chunks;
     // The counter is bumped with a hand-issued atomic whose result stays in a vector register until the
     // unit is started (one unit later): the compiler's own atomic sequence waits for the round trip at
-    // once.  The compiler does not count this load, hence the explicit wait before the value is used;
-    // by then the only other loads in flight are the next chunk's, which are needed at that point anyway.
+    // once.  The asm narrows exec to lane 0 itself (the loop is wave-uniform, all lanes active), so no
+    // branch and no merge of register values surrounds it, and it takes next_raw as an in/out operand.
+    // The compiler does not count this load, hence the explicit wait, in one asm statement with the read
+    // of the register: nothing can touch the register between the issue and the wait.  By then the only
+    // other loads in flight are the next chunk's, which are needed at that point anyway.
     unsigned static_next = blockIdx.x * WAVES + wave;     // queue == NULL: units in fixed round-robin order
-    auto take = [&]() -> unsigned {
-        unsigned v = 0;
+    auto take = [&](unsigned v) -> unsigned {
         if (queue == nullptr) {
             v = static_next;
             static_next += n_waves;
-        } else if (lane == 0) {
+        } else {
             const unsigned one = 1u;
-            asm volatile("global_atomic_add %0, %1, %2, off sc0" : "=v"(v) : "v"(queue), "v"(one) : "memory");
+            unsigned long long saved;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, 1\n\tglobal_atomic_add %0, %2, %3, off sc0\n\ts_mov_b64 exec, %1"
+                         : "+v"(v), "=&s"(saved)
+                         : "v"(queue), "v"(one)
+                         : "memory");
         }
         return v;
     };
     auto uniform = [&](unsigned v) {
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v)::"memory");
-        return n_waves + (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+        unsigned raw;
+        if (queue == nullptr) {
+            raw = v;
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(raw) : "v"(v) : "memory");
+        }
+        return n_waves + raw;
     };
     unsigned unit = blockIdx.x * WAVES + wave, next_raw = 0, in_unit = 0;
     unsigned chunk = unit * UNIT;
@@ -720,7 +731,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         const int64_t t0_cur = t0;
         // the counter is bumped right after the top-of-loop wait of a unit's second chunk, so the atomic
         // has two chunks to return before anything waits on the memory counter again
-        if (in_unit == 1) next_raw = take();
+        if (in_unit == 1) next_raw = take(next_raw);
         if (++in_unit == UNIT) {
             in_unit = 0;
             unit = uniform(next_raw);

@@ -35,6 +35,10 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
                     if (KIND == 9) asm volatile("v_add_u32 %0, %0, %1" : "+v"(v[n]) : "v"(bv));
                     if (KIND == 10) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(v[n]));
                     if (KIND == 11) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(p[n]) : "v"(pb));
+                    if (KIND == 12) asm volatile("v_med3_f32 %0, %0, %1, %1" : "+v"(v[n]) : "v"(bv));
+                    if (KIND == 13) asm volatile("v_rndne_f32 %0, %0" : "+v"(v[n]));
+                    if (KIND == 14) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(v[n]) : "v"(bv));
+                    if (KIND == 15) asm volatile("v_exp_f32 %0, %0" : "+v"(v[n]));
                 }
             }
     }
@@ -44,23 +48,23 @@ __global__ __launch_bounds__(256) void k(float *out, int iters, float a, float b
     out[blockIdx.x * 256 + threadIdx.x] = s;
 }
 template <int KIND>
-void run(const char *name) {
+void run(const char *name, int waves = 1) {
     const int iters = 2000;
     float *out;
-    hipMalloc(&out, 256 * 8 * 256 * sizeof(float));
+    hipMalloc(&out, 256 * 8 * 256 * sizeof(float));   // up to 8 workgroups per CU
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    hipLaunchKernelGGL((k<KIND>), dim3(256), dim3(256), 0, 0, out, 10, 1.f, 2.f);
+    hipLaunchKernelGGL((k<KIND>), dim3(256 * waves), dim3(256), 0, 0, out, 10, 1.f, 2.f);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((k<KIND>), dim3(256), dim3(256), 0, 0, out, iters, 1.f, 2.f);
+    hipLaunchKernelGGL((k<KIND>), dim3(256 * waves), dim3(256), 0, 0, out, iters, 1.f, 2.f);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms;
     hipEventElapsedTime(&ms, e0, e1);
-    const double per = ms * 1e6 / (iters * 16.0);
-    printf("%-28s %.1f ns per (MFMA + 8 instr): %.2f ns per instruction on top of 14.5\n", name, per, (per - 14.5) / 8);
+    const double per = ms * 1e6 / (iters * 16.0) / waves;   // per MFMA per SIMD
+    printf("%-28s waves/SIMD %d: %.1f ns per (MFMA + 8 instr): %.2f ns per instruction on top of 14.5\n", name, waves, per, (per - 14.5) / 8);
     hipFree(out);
 }
 int main() {
@@ -76,5 +80,14 @@ int main() {
     run<9>("v_add_u32");
     run<10>("v_lshlrev_b32");
     run<11>("v_pk_add_f32");
+    run<12>("v_med3_f32");
+    run<13>("v_rndne_f32");
+    run<14>("v_cndmask_b32");
+    run<15>("v_exp_f32");
+    run<0>("v_fma_f32", 2);
+    run<0>("v_fma_f32", 4);
+    run<5>("v_pk_fma_f32", 4);
+    run<2>("v_mov_b32", 4);
+    run<12>("v_med3_f32", 4);
     return 0;
 }
