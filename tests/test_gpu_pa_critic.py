@@ -179,9 +179,10 @@ def test_gradient_penalty_vs_oracle_ragged(shape, critic_impl):
         close(lin.weight_orig.grad, rg, rtol=3e-4, atol=3e-6)
 
 
-@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099])
+@pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099, 600013])
 def test_critic_ragged_sizes_vs_oracle(n, critic_impl):
-    """Sample counts around the 16-sample tile: forward, input gradient and weight gradient."""
+    """Sample counts around the 16-sample tile: forward, input gradient and weight gradient.  The largest
+    gives every wave of the MFMA kernels more than two units of the tile counter and a ragged last tile."""
     from oracle import critic as oc
     from dpd_amd.models import Discriminator
     torch.manual_seed(n)
@@ -205,11 +206,19 @@ def test_critic_ragged_sizes_vs_oracle(n, critic_impl):
     scale = float(ref.abs().max())
     close(out, ref.detach(), rtol=1e-5, atol=1e-5 * scale)
     out.backward(gs.to(DEV))
-    close(xg.grad, rg[0], rtol=1e-4, atol=1e-5 * float(rg[0].abs().max()))
+    if n < 100000:
+        close(xg.grad, rg[0], rtol=1e-4, atol=1e-5 * float(rg[0].abs().max()))
+    else:
+        # among ~7e7 pre-activations a few lie within fp32 rounding of zero, where the summation order
+        # decides the side of the LeakyReLU kink: at most 1e-5 of the samples may differ
+        bad = ~np.isclose(xg.grad.cpu().numpy(), rg[0].numpy(), rtol=1e-4, atol=1e-5 * float(rg[0].abs().max()))
+        assert bad.any(axis=1).sum() <= n * 1e-5, int(bad.any(axis=1).sum())
     i = 1
+    # sums over n samples in fp32 on both sides, in different orders: the absolute term grows with n
+    wtol = 1e-5 if n < 100000 else 5e-4
     for lin in d._layers():
-        close(lin.bias.grad, rg[i], rtol=3e-4, atol=1e-5 * float(rg[i].abs().max())); i += 1
-        close(lin.weight_orig.grad, rg[i], rtol=3e-4, atol=1e-5 * float(rg[i].abs().max())); i += 1
+        close(lin.bias.grad, rg[i], rtol=3e-4, atol=wtol * float(rg[i].abs().max())); i += 1
+        close(lin.weight_orig.grad, rg[i], rtol=3e-4, atol=wtol * float(rg[i].abs().max())); i += 1
 
 
 # ------------------------------------------------------------------ fused generator -> PA chain
