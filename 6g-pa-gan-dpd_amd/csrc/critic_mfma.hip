@@ -26,11 +26,36 @@ DEV f32x4 mfma_blocks(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_
 constexpr int WAVES = 4;
 // waves per workgroup of the weight-gradient kernels: one operand image serves all of them, so a large
 // workgroup is what lets a third wave per SIMD fit into the LDS (12: 146 KiB, one workgroup per CU)
+#ifndef CRITIC_BF16X3
+#define CRITIC_BF16X3 1
+#endif
 #ifndef WG_WAVES
-#define WG_WAVES 4
+#define WG_WAVES (CRITIC_BF16X3 ? 8 : 4)   // the bf16 image is 48 KiB: eight waves share one per CU
 #endif
 constexpr int WG_PER_CU = WG_WAVES == 4 ? 2 : 1;
+constexpr int NOGRAD_PER_CU = CRITIC_BF16X3 ? 3 : 4;   // workgroups per CU of the kernels without a transposition buffer (LDS)
 // operand image: quads of four consecutive k-steps per lane
+#if CRITIC_BF16X3
+// The hidden-layer products run on the bf16 matrix cores with both operands split three ways into bf16
+// (x = hi + mid + lo, each the bf16 rounding of what the previous terms leave; six products hh, hm, mh, hl,
+// lh, mm accumulated in fp32, small terms first): the error against fp64 is that of the fp32 MFMA, six
+// v_mfma_f32_16x16x32_bf16 replace eight v_mfma_f32_16x16x4_f32 at 8 ns instead of 14.5 ns each, and VALU
+// work issues in their shadow, which it does not for the fp32 MFMA.  A 16-byte image entry holds eight
+// bf16 of one term: k = 8 * lane group + e, where e < 4 is neuron 4g + e of one 16-row result tile and
+// e >= 4 neuron 4g + e - 4 of the next tile (exactly what a lane holds after the previous layer).
+constexpr int Q_A1 = 0;     // [t]            e = t : W1[16t + i][g]  (FC1, K = 4, stays on the fp32 MFMA)
+constexpr int Q_W1C = 1;    // [c][t]         e = r : W1[16t + 4g + r][c], c = 0, 1 (the two x columns; VALU operand)
+constexpr int Q_B1 = 9;     // [t]            e = r : b1[16t + 4g + r]
+constexpr int Q_B2 = 13;    // [u]            e = r : b2[16u + 4g + r]
+constexpr int Q_B3 = 15;    //                e = r : b3[4g + r]
+constexpr int Q_B4 = 16;    //                e = 0 : b4, else 0
+constexpr int Q_W4 = 17;    //                e = r : W4[4g + r] (VALU operand)
+constexpr int QB_A2 = 18;   // [u][q][term]   W2[16u + i][neuron(q, g, e)], neuron = 16(2q + (e >> 2)) + 4g + (e & 3)
+constexpr int QB_A3 = 30;   // [term]         W3[i][16(e >> 2) + 4g + (e & 3)]
+constexpr int QB_A2T = 33;  // [t][term]      W2[16(e >> 2) + 4g + (e & 3)][16t + i]
+constexpr int QB_A3T = 45;  // [term]         W3[4g + (e & 3)][16(e >> 2) + i]  (two 16x16x16 operands in one entry)
+constexpr int NQUAD = 48;
+#else
 constexpr int Q_A1 = 0;     // [t]            e = t : W1[16t + i][g]
 constexpr int Q_A2 = 1;     // [u][t]         e = r : W2[16u + i][16t + 4g + r]
 constexpr int Q_A3 = 9;     // [u]            e = r : W3[i][16u + 4g + r]
@@ -43,6 +68,7 @@ constexpr int Q_B3 = 35;    //                e = r : b3[4g + r]
 constexpr int Q_B4 = 36;    //                e = 0 : b4, else 0
 constexpr int Q_W4 = 37;    //                e = r : W4[4g + r] (VALU operand)
 constexpr int NQUAD = 38;
+#endif
 constexpr int IMG_WORDS = NQUAD * 64 * 4;          // 9728
 // per-wave transposition buffer
 constexpr int P64 = 80, P32 = 48, P16 = 16;        // row pitches: 16 mod 32 -> rows s, s+1 hit different bank halves
@@ -53,6 +79,57 @@ static_assert(LDS_WORDS >= WG_WAVES * C_SLAB, "gradient rows are combined in the
 
 DEV int swz(int s) { return 4 * ((s >> 1) & 3); }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+
+// x = h + m + l to 24 bits: each term is the bf16 rounding of what the previous terms leave
+DEV void split3(float x, __bf16 &h, __bf16 &m, __bf16 &l) {
+    h = (__bf16)x;
+    const float r1 = x - (float)h;
+    m = (__bf16)r1;
+    l = (__bf16)(r1 - (float)m);
+}
+
+#if CRITIC_BF16X3
+DEV void build_image(float *img, const float *__restrict__ wb) {
+    for (int idx = threadIdx.x; idx < NQUAD * 64; idx += blockDim.x) {
+        const int q = idx >> 6, lane = idx & 63, i = lane & 15, g = lane >> 4;
+        if (q < QB_A2) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x;
+                if (q == Q_A1) x = wb[C_W1 + (16 * e + i) * 4 + g];
+                else if (q < Q_B1) { int c = (q - Q_W1C) >> 2, t = (q - Q_W1C) & 3; x = wb[C_W1 + (16 * t + 4 * g + e) * 4 + c]; }
+                else if (q < Q_B2) { int t = q - Q_B1; x = wb[C_B1 + 16 * t + 4 * g + e]; }
+                else if (q < Q_B3) { int u = q - Q_B2; x = wb[C_B2 + 16 * u + 4 * g + e]; }
+                else if (q == Q_B3) x = wb[C_B3 + 4 * g + e];
+                else if (q == Q_B4) x = e == 0 ? wb[C_B4] : 0.f;
+                else x = wb[C_W4 + 4 * g + e];
+                v[e] = x;
+            }
+            reinterpret_cast<f32x4 *>(img)[idx] = v;
+        } else {
+            int term;
+            bf16x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int n = 16 * (e >> 2) + 4 * g + (e & 3);     // neuron inside a pair of 16-row tiles
+                float x;
+                if (q < QB_A3) { int k = q - QB_A2; term = k % 3; int u = k / 6, qq = (k / 3) & 1; x = wb[C_W2 + (16 * u + i) * 64 + 32 * qq + n]; }
+                else if (q < QB_A2T) { term = q - QB_A3; x = wb[C_W3 + i * 32 + n]; }
+                else if (q < QB_A3T) { int k = q - QB_A2T; term = k % 3; int t = k / 3; x = wb[C_W2 + n * 64 + 16 * t + i]; }
+                else { term = q - QB_A3T; x = wb[C_W3 + (4 * g + (e & 3)) * 32 + 16 * (e >> 2) + i]; }
+                __bf16 h, m, l;
+                split3(x, h, m, l);
+                v[e] = term == 0 ? h : (term == 1 ? m : l);
+            }
+            reinterpret_cast<bf16x8 *>(img)[idx] = v;
+        }
+    }
+    __syncthreads();
+}
+#else
 DEV void build_image(float *img, const float *__restrict__ wb) {
     for (int idx = threadIdx.x; idx < NQUAD * 64; idx += blockDim.x) {
         const int q = idx >> 6, lane = idx & 63, i = lane & 15, g = lane >> 4;
@@ -77,6 +154,7 @@ DEV void build_image(float *img, const float *__restrict__ wb) {
     }
     __syncthreads();
 }
+#endif
 
 DEV f32x4 quad(const float *img, int q, int lane) { return reinterpret_cast<const f32x4 *>(img)[q * 64 + lane]; }
 
@@ -146,6 +224,220 @@ DEV float sum_over_groups(float v) {
 struct NoPre {
     DEV void operator()() const {}
 };
+struct InOps {         // W1[:, 0:2] per neuron, VALU operands
+    f32x4 w0[4], w1[4];
+};
+DEV void load_ops(InOps &o, const float *img, int lane) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        o.w0[t] = quad(img, Q_W1C + t, lane);
+        o.w1[t] = quad(img, Q_W1C + 4 + t, lane);
+    }
+}
+
+#if CRITIC_BF16X3
+DEV bf16x8 bquad(const float *img, int q, int lane) { return reinterpret_cast<const bf16x8 *>(img)[q * 64 + lane]; }
+struct B3 {            // eight values per lane, split three ways
+    bf16x8 h, m, l;
+};
+DEV void load_b3(B3 &o, const float *img, int q, int lane) {
+    o.h = bquad(img, q, lane);
+    o.m = bquad(img, q + 1, lane);
+    o.l = bquad(img, q + 2, lane);
+}
+// the eight values a lane holds of a pair of 16-row result tiles -> three bf16 operands
+DEV void split8(B3 &o, const f32x4 &x0, const f32x4 &x1) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 h, m, l;
+        split3(e < 4 ? x0[e] : x1[e - 4], h, m, l);
+        o.h[e] = h;
+        o.m[e] = m;
+        o.l[e] = l;
+    }
+}
+DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// c + a x b to fp32 accuracy: two chains of three products each, small terms first
+DEV void mfma6(f32x4 &lo, f32x4 &hi, const B3 &a, const B3 &b) {
+    lo = mfma_bf(a.m, b.m, lo);
+    hi = mfma_bf(a.m, b.h, hi);
+    lo = mfma_bf(a.l, b.h, lo);
+    hi = mfma_bf(a.h, b.m, hi);
+    lo = mfma_bf(a.h, b.l, lo);
+    hi = mfma_bf(a.h, b.h, hi);
+}
+
+struct FrontOps {      // FC1 weights and accumulator start (b1), FC2 accumulator start (b2), FC2 weights of the first k-step
+    f32x4 a1, b1[4], b2[2];
+    B3 w[2];
+};
+struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 for the VALU last layer
+    f32x4 b3, w4;
+    B3 w;
+};
+struct TopOps {        // W3^T: both 16-row tiles of a 16x16x16 operand in one entry per term
+    bf16x8 t[3];
+};
+struct BotOps {        // W2^T, row tiles 0 and 1
+    B3 w[2];
+};
+DEV void load_ops(FrontOps &o, const float *img, int lane) {
+    o.a1 = quad(img, Q_A1, lane);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) o.b1[t] = quad(img, Q_B1 + t, lane);
+    o.b2[0] = quad(img, Q_B2, lane);
+    o.b2[1] = quad(img, Q_B2 + 1, lane);
+    load_b3(o.w[0], img, QB_A2, lane);
+    load_b3(o.w[1], img, QB_A2 + 6, lane);
+}
+DEV void load_ops(Fc3Ops &o, const float *img, int lane) {
+    o.b3 = quad(img, Q_B3, lane);
+    o.w4 = quad(img, Q_W4, lane);
+    load_b3(o.w, img, QB_A3, lane);
+}
+DEV void load_ops(TopOps &o, const float *img, int lane) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) o.t[k] = bquad(img, QB_A3T + k, lane);
+}
+DEV void load_ops(BotOps &o, const float *img, int lane) {
+    load_b3(o.w[0], img, QB_A2T, lane);
+    load_b3(o.w[1], img, QB_A2T + 3, lane);
+}
+
+// z0, z1 += W2 (rows 0..15 | 16..31) x src, src = 64 values per sample in four quads, two k-steps of 32.
+// ACT: src holds FC1 pre-activations; LeakyReLU is applied on the way in.  pre() runs before the second
+// k-step.  The splits and activations of the second step sit in the shadow of the first step's MFMAs.
+template <bool ACT, bool BITS, class Pre>
+DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], const B3 (&w)[2], f32x4 (&m)[4], unsigned &bits,
+                   const float *img, int lane, float slope, Pre pre, unsigned long long *ts = nullptr) {
+    if (ACT) {
+        act4<BITS>(src[0], slope, src[0], m[0], bits, 0);
+        act4<BITS>(src[1], slope, src[1], m[1], bits, 4);
+    }
+    B3 n[2], b;
+    load_b3(n[0], img, QB_A2 + 3, lane);
+    load_b3(n[1], img, QB_A2 + 9, lane);
+    split8(b, src[0], src[1]);
+    FENCE();
+    f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
+    mfma6(y0, z0, w[0], b);
+    mfma6(y1, z1, w[1], b);
+    if (ACT) {
+        act4<BITS>(src[2], slope, src[2], m[2], bits, 8);
+        act4<BITS>(src[3], slope, src[3], m[3], bits, 12);
+    }
+    B3 b2;
+    split8(b2, src[2], src[3]);
+    TS(2)
+    FENCE();
+    pre();
+    FENCE();
+    mfma6(y0, z0, n[0], b2);
+    mfma6(y1, z1, n[1], b2);
+    FENCE();
+    z0 += y0;
+    z1 += y1;
+    TS(3)
+}
+
+// forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).
+template <bool BITS = false, class Pre>
+DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope, const FrontOps &o, Pre pre,
+                       unsigned long long *ts = nullptr) {
+    a.bits = 0u;
+    TS(0)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, o.b1[t]);
+    TS(1)
+    f32x4 z0 = o.b2[0], z1 = o.b2[1];
+    fc2_block<true, BITS>(z0, z1, a.h1, o.w, a.m1, a.bits, img, lane, slope, pre, ts);
+    act4<BITS>(z0, slope, a.h2[0], a.m2[0], a.bits, 16);
+    act4<BITS>(z1, slope, a.h2[1], a.m2[1], a.bits, 20);
+    TS(6)
+}
+// y = W3 x (16 outputs from the 32 values of a tile pair), on top of `start`
+DEV f32x4 fc3_product(const f32x4 &x0, const f32x4 &x1, const B3 &w, f32x4 start) {
+    B3 b;
+    split8(b, x0, x1);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+    mfma6(lo, start, w, b);
+    return start + lo;
+}
+// FC3 and the last layer (16 -> 1), which runs on the VALU: four FMAs per lane and a sum over the lane groups
+template <bool BITS = false, class Pre>
+DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc3Ops &o, Pre pre,
+                      unsigned long long *ts = nullptr) {
+    TS(7)
+    pre();
+    FENCE();
+    const f32x4 y = fc3_product(a.h2[0], a.h2[1], o.w, o.b3);
+    FENCE();
+    TS(8)
+    act4<BITS>(y, slope, a.h3, a.m3, a.bits, 24);
+    float s = o.w4[0] * a.h3[0];
+#pragma unroll
+    for (int r = 1; r < 4; ++r) s = __builtin_fmaf(o.w4[r], a.h3[r], s);
+    a.score = sum_over_groups(s) + img[(Q_B4 * 64 + lane) * 4];
+    TS(9)
+}
+
+// back-propagation of an upstream vector through the three hidden layers, in two steps:
+//   top[r] (16 values on neurons 4g + r of layer 3, already masked) -> d2[2] (layer 2, masked) -> d1[4] (layer 1, masked)
+// The first step contracts over 16 neurons: v_mfma_f32_16x16x16_bf16, whose k = 4g + e is what a lane holds.
+template <class Pre>
+DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps &o, Pre pre) {
+    pre();
+    s16x4 b[3];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        __bf16 h, m, l;
+        split3(top[e], h, m, l);
+        b[0][e] = __builtin_bit_cast(short, h);
+        b[1][e] = __builtin_bit_cast(short, m);
+        b[2][e] = __builtin_bit_cast(short, l);
+    }
+    FENCE();
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
+    // products in the order mm, lh, hl, mh, hm, hh (term of the weights, term of the activations)
+    const int ta[6] = {1, 2, 0, 1, 0, 0}, tb[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        typedef short s16x8 __attribute__((ext_vector_type(8)));
+        const s16x8 w = __builtin_bit_cast(s16x8, o.t[ta[k]]);
+        e0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[0], w[1], w[2], w[3]}, b[tb[k]], e0, 0, 0, 0);
+        e1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[4], w[5], w[6], w[7]}, b[tb[k]], e1, 0, 0, 0);
+    }
+    FENCE();
+    d2[0] = e0 * m2[0];
+    d2[1] = e1 * m2[1];
+}
+// pre() runs before the second half
+template <class Pre>
+DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f32x4 (&m1)[4], f32x4 (&d1)[4], const BotOps &o,
+                      Pre pre) {
+    B3 w2[2], b;
+    load_b3(w2[0], img, QB_A2T + 6, lane);
+    load_b3(w2[1], img, QB_A2T + 9, lane);
+    split8(b, d2[0], d2[1]);
+    FENCE();
+    f32x4 f[4], flo[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        f[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        flo[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    mfma6(flo[0], f[0], o.w[0], b);
+    mfma6(flo[1], f[1], o.w[1], b);
+    FENCE();
+    pre();
+    FENCE();
+    mfma6(flo[2], f[2], w2[0], b);
+    mfma6(flo[3], f[3], w2[1], b);
+    FENCE();
+#pragma unroll
+    for (int t = 0; t < 4; ++t) d1[t] = (f[t] + flo[t]) * m1[t];
+}
+#else
 struct FrontOps {      // FC1 weights and accumulator start (b1), FC2 accumulator start (b2), first FC2 weight pair
     f32x4 a1, b1[4], b2[2], w0, w1;
 };
@@ -157,9 +449,6 @@ struct TopOps {        // W3^T
 };
 struct BotOps {        // W2^T, first half (u = 0)
     f32x4 w[4];
-};
-struct InOps {         // W1[:, 0:2] per neuron, VALU operands
-    f32x4 w0[4], w1[4];
 };
 DEV void load_ops(FrontOps &o, const float *img, int lane) {
     o.a1 = quad(img, Q_A1, lane);
@@ -184,14 +473,6 @@ DEV void load_ops(BotOps &o, const float *img, int lane) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) o.w[t] = quad(img, Q_A2T + 2 * t, lane);
 }
-DEV void load_ops(InOps &o, const float *img, int lane) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        o.w0[t] = quad(img, Q_W1C + t, lane);
-        o.w1[t] = quad(img, Q_W1C + 4 + t, lane);
-    }
-}
-
 // z0, z1 += W2 (rows 0..15 | 16..31) x src, src = 64 values per sample in four quads.  ACT: src holds FC1
 // pre-activations; LeakyReLU is applied on the way in.  pre() runs before the last group.
 template <bool ACT, bool BITS, class Pre>
@@ -302,6 +583,8 @@ DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f3
 #pragma unroll
     for (int t = 0; t < 4; ++t) d1[t] = f[t] * m1[t];
 }
+
+#endif
 
 // (W1[:, 0:2])^T d1 -> the two input-gradient components, in every lane of sample j.  Two of sixteen
 // rows of an MFMA tile would be used, so this runs on the VALU: 32 FMAs per lane over its 16 neurons,
@@ -987,27 +1270,37 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         P2R p2r;
         P3R p3r;
         unsigned no_bits = 0u;
-        fc2_block<false, false>(z0, z1, du1, front.w0, front.w1, m1, no_bits, lds, lane, slope, [&] {
+        auto pre_fc2 = [&] {
             load_ops(o3, lds, lane);
             read_p1(p1r, ad);           // previous tile's v1 x gh
-        });
+        };
+#if CRITIC_BF16X3
+        fc2_block<false, false>(z0, z1, du1, front.w, m1, no_bits, lds, lane, slope, pre_fc2);
+#else
+        fc2_block<false, false>(z0, z1, du1, front.w0, front.w1, m1, no_bits, lds, lane, slope, pre_fc2);
+#endif
         mfma_p1(ac, p1r);
         f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
         // every outer-product phase is parked as soon as its factors exist and run after the next block of
         // chain MFMAs (which covers the LDS round trip): p3 = du2 x v3, p2 = du1 x v2, p1 = v1 x gh
         park_p3(ad, du2, v3);
         // dv3 = W3 du2 ; dW4 += dv3 * D3
-        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
         load_ops(top, lds, lane);
         read_p3(p3r, ad);
         FENCE();
+#if CRITIC_BF16X3
+        const f32x4 dv3 = fc3_product(du2[0], du2[1], o3.w, f32x4{0.f, 0.f, 0.f, 0.f});
+#else
+        f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             y0 = mfma4(o3.w30[r], du2[0][r], y0);
             y1 = mfma4(o3.w31[r], du2[1][r], y1);
         }
+        const f32x4 dv3 = y0 + y1;
+#endif
         FENCE();
-        dw4 += (y0 + y1) * m3;
+        dw4 += dv3 * m3;
         mfma_p3(ac, p3r);
         chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); });
         park_p2(ad, du1, v2);
@@ -1069,7 +1362,7 @@ static int init_attrs() {
 
 int critic_mfma_forward(const float *x, const float *cond, int64_t N, const float *wb, float slope, float *score,
                         float *score_sum, hipStream_t st) {
-    const int grid = grid_tiles(N, 4);
+    const int grid = grid_tiles(N, NOGRAD_PER_CU);
     hipLaunchKernelGGL(k_critic_fwd_mfma, dim3(grid), dim3(WAVES * 64), 0, st, x, cond, N, wb, slope, score, score_sum);
     DPD_LAUNCH_CHECK();
     return DPD_OK;
@@ -1096,7 +1389,7 @@ int critic_mfma_backward(const float *x, const float *cond, int64_t N, const flo
         // no slab in this variant: the workspace, when there is one, only holds the counter
         rc = tile_counter(reinterpret_cast<unsigned *>(ws), st, &queue);
         if (rc) return rc;
-        hipLaunchKernelGGL((k_critic_bwd_mfma<false, true>), dim3(grid_tiles(N, 4)), dim3(WAVES * 64), IMG_LDS, st, x, cond, N, wb,
+        hipLaunchKernelGGL((k_critic_bwd_mfma<false, true>), dim3(grid_tiles(N, NOGRAD_PER_CU)), dim3(WAVES * 64), IMG_LDS, st, x, cond, N, wb,
                            slope, gscore, gconst, gx2, nullptr, score_sum, queue);
         DPD_LAUNCH_CHECK();
         return DPD_OK;
@@ -1140,7 +1433,7 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
     rc = tile_counter(counters, st, &queue);
     if (rc) return rc;
     unsigned *queue_c = queue ? queue + 1 : nullptr;
-    const int ga = grid_tiles(N, 4);
+    const int ga = grid_tiles(N, NOGRAD_PER_CU);
     if (row1)
         hipLaunchKernelGGL((k_gp_a_mfma<true>), dim3(ga), dim3(WAVES * 64), 0, st, real, fake, cond, alpha, N, L, wb, slope,
                            g, maskw, tile_sq, queue);
