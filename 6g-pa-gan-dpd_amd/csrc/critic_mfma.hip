@@ -245,16 +245,31 @@ DEV void load_b3(B3 &o, const float *img, int q, int lane) {
     o.m = bquad(img, q + 1, lane);
     o.l = bquad(img, q + 2, lane);
 }
+// Two fp32 values -> their three bf16 terms, packed in pairs.  hi and mid are the upper 16 bits of the
+// value and of what it leaves (truncation: the mask gives the term as a float at once, the subtraction is
+// exact, and a byte permute packs the pair), lo is the bf16 rounding of the rest: 9 VALU instructions per
+// pair where round-to-nearest terms need 11.  x = hi + mid + lo to 24 bits either way.
+DEV void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    l = __builtin_bit_cast(unsigned, bf16x2{(__bf16)q0, (__bf16)q1});
+}
 // the eight values a lane holds of a pair of 16-row result tiles -> three bf16 operands
 DEV void split8(B3 &o, const f32x4 &x0, const f32x4 &x1) {
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        __bf16 h, m, l;
-        split3(e < 4 ? x0[e] : x1[e - 4], h, m, l);
-        o.h[e] = h;
-        o.m[e] = m;
-        o.l[e] = l;
-    }
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    unsigned h[4], m[4], l[4];
+    split_pair(x0[0], x0[1], h[0], m[0], l[0]);
+    split_pair(x0[2], x0[3], h[1], m[1], l[1]);
+    split_pair(x1[0], x1[1], h[2], m[2], l[2]);
+    split_pair(x1[2], x1[3], h[3], m[3], l[3]);
+    o.h = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+    o.m = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+    o.l = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
 }
 DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 // c + a x b to fp32 accuracy: two chains of three products each, small terms first
@@ -387,15 +402,12 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
 template <class Pre>
 DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps &o, Pre pre) {
     pre();
-    s16x4 b[3];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        __bf16 h, m, l;
-        split3(top[e], h, m, l);
-        b[0][e] = __builtin_bit_cast(short, h);
-        b[1][e] = __builtin_bit_cast(short, m);
-        b[2][e] = __builtin_bit_cast(short, l);
-    }
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    unsigned bh[2], bm[2], bl[2];
+    split_pair(top[0], top[1], bh[0], bm[0], bl[0]);
+    split_pair(top[2], top[3], bh[1], bm[1], bl[1]);
+    const s16x4 b[3] = {__builtin_bit_cast(s16x4, u32x2{bh[0], bh[1]}), __builtin_bit_cast(s16x4, u32x2{bm[0], bm[1]}),
+                        __builtin_bit_cast(s16x4, u32x2{bl[0], bl[1]})};
     FENCE();
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
     // products in the order mm, lh, hl, mh, hm, hh (term of the weights, term of the activations)
