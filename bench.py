@@ -187,7 +187,10 @@ def run_stage2(ctx, args, steps, warmup):
         + (GEN_FWD_MAC + CRITIC_FWD_MAC + CRITIC_DX_MAC + GEN_BWD_MAC)
     flop = 2.0 * mac * ctx.n_local
     t = dt / steps
-    roof = {"bound": "mfma", "kernel": "whole step (critic kernels dominate)", "achieved": flop / t / 1e12,
+    # the critic's hidden-layer products run on the bf16 matrix cores (three-way split operands, fp32
+    # accuracy): "achieved" is in fp32-equivalent flops and "frac" compares it with the fp32 peak
+    roof = {"bound": "mfma", "kernel": "whole step (critic kernels dominate; fp32-equivalent flops, part on bf16 matrix cores)",
+            "achieved": flop / t / 1e12,
             "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / t / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
             "flop_per_sample": 2 * mac}
     return dt, roof, {"g_total": float(info["g_total"].item())}
