@@ -39,7 +39,21 @@ constexpr int ZERO_W = 360;         // 64 words that always hold 0: operand of t
 constexpr int ONE_W = 424;          // 64 words that always hold 1: slot 30 is the bias input (its W1 column is b1,
                                     // its dW1 row is the bias gradient)
 constexpr int TG_W = 488;           // 64 x float2: the chunk's target / upstream gradient, sample-major (backward only)
-constexpr int SER_WORDS = 616;
+// Experiment, off by default (-DGEN_FC1_BF16=1): FC1 of the fused backward kernel on the bf16 matrix cores
+// with both operands split three ways into bf16 (x = hi + mid + lo to 24 bits, six products, fp32
+// accumulation: the accuracy of the fp32 MFMA with 12 MFMAs of 8 ns instead of 16 of 14.5 ns).  The series
+// are then also staged as bf16 terms: three planes (hi, mid, lo) of seven rows of 72 halfwords: the five
+// series, a row of ones (slot 30; zero in the mid and lo planes) and a row of zeros (slot 31).  Parity
+// holds, but the kernel is 7 % slower (1.18 ms against 1.10 ms): 24 halfword reads and 12 packing
+// instructions per tile instead of 8 word reads, plus the splits at staging time, cost more than the MFMAs
+// save; it would take ds_read_u16_d16(_hi) loads and fewer staged terms to turn this around.
+#ifndef GEN_FC1_BF16
+#define GEN_FC1_BF16 0
+#endif
+constexpr int BF_W = 616;           // word offset of the bf16 planes
+constexpr int BF_ROW = 72;          // halfwords per row
+constexpr int BF_PLANE = 7 * BF_ROW;   // halfwords per plane
+constexpr int SER_WORDS = GEN_FC1_BF16 ? BF_W + 3 * BF_PLANE / 2 : BF_W;   // 1372 | 616
 constexpr int P32 = 48;             // row pitch of the transposition tiles (16 mod 32)
 // backward: two tile buffers per wave (two tiles are in flight), each = [16 samples][gz1 (32) | gz2 (16)] and
 // [16 samples][h1 (32) | unused (16)], both with the 48-word pitch and the XOR swizzle of swz()
@@ -48,7 +62,7 @@ constexpr int GZ_W = SER_WORDS;                  // + TILE_W * buffer
 constexpr int H1_W = GZ_W + 16 * P32;
 constexpr int BWD_WORDS = SER_WORDS + 2 * TILE_W;   // 3688 words per wave
 static_assert(WAVES * BWD_WORDS >= WAVES * G_SLAB, "the gradient rows are combined in the staging LDS");
-static_assert(WAVES * BWD_WORDS * 4 <= 65536, "static LDS limit");
+constexpr size_t BWD_LDS_BYTES = (size_t)WAVES * BWD_WORDS * sizeof(float);   // 58 KiB (71 KiB with the bf16 planes): dynamic LDS, two workgroups per CU
 
 DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -67,6 +81,25 @@ DEV int slot_word(int slot) {
     return SER_BASE0 + SER_STRIDE * type + 5 - tap;
 }
 DEV int swz(int s) { return 4 * ((s >> 1) & 3); }
+// halfword offset inside a bf16 plane of (slot, sample 0 of tile 0); add sample index and 16 * tile
+DEV int slot_half(int slot) {
+    if (slot >= 30) return (slot == 30 ? 5 : 6) * BF_ROW;
+    int type = slot / 6, tap = slot - 6 * type;
+    return type * BF_ROW + 5 - tap;
+}
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// x = h + m + l to 24 bits as bf16 bit patterns: h and m by truncation (the masked value is the term as a
+// float, the subtraction is exact), l by rounding
+DEV void split3(float x, unsigned short &h, unsigned short &m, unsigned short &l) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    h = (unsigned short)(u >> 16);
+    const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
+    const unsigned v = __builtin_bit_cast(unsigned, r1);
+    m = (unsigned short)(v >> 16);
+    const float r2 = r1 - __builtin_bit_cast(float, v & 0xffff0000u);
+    l = __builtin_bit_cast(unsigned short, (__bf16)r2);
+}
 
 struct Lane {
     int lane, j, g;
@@ -108,7 +141,80 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
         p[2 * SER_STRIDE] = e;
         p[3 * SER_STRIDE] = e2;
         p[4 * SER_STRIDE] = e4;
+        if (GEN_FC1_BF16) {
+            unsigned short *bp = reinterpret_cast<unsigned short *>(ser + BF_W) + tau;
+            const float val[5] = {v.x, v.y, e, e2, e4};
+#pragma unroll
+            for (int type = 0; type < 5; ++type) {
+                unsigned short h, m, l;
+                split3(val[type], h, m, l);
+                bp[type * BF_ROW] = h;
+                bp[BF_PLANE + type * BF_ROW] = m;
+                bp[2 * BF_PLANE + type * BF_ROW] = l;
+            }
+        }
     }
+}
+// the constant rows of the bf16 planes (once per wave)
+DEV void init_planes(float *ser, int lane) {
+    unsigned short *bp = reinterpret_cast<unsigned short *>(ser + BF_W);
+    for (int k = lane; k < BF_ROW; k += 64) {
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            bp[pl * BF_PLANE + 5 * BF_ROW + k] = pl == 0 ? (unsigned short)0x3f80 : (unsigned short)0;   // 1.0
+            bp[pl * BF_PLANE + 6 * BF_ROW + k] = 0;
+        }
+    }
+}
+// FC1 operands of a lane: W1 rows 16t + i over the eight slots 8g + e, three terms each
+struct Fc1Weights {
+    bf16x8 a[2][3];
+};
+DEV void load_fc1_weights(Fc1Weights &w, const float *__restrict__ wq, int j, int g) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        unsigned short h[8], m[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int slot = 8 * g + e, ref = slot_ref(slot);
+            const float x = ref >= 0 ? wq[G_W1 + (16 * t + j) * 30 + ref] : (slot == 30 ? wq[G_B1 + 16 * t + j] : 0.f);
+            split3(x, h[e], m[e], l[e]);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            w.a[t][0][e] = __builtin_bit_cast(__bf16, h[e]);
+            w.a[t][1][e] = __builtin_bit_cast(__bf16, m[e]);
+            w.a[t][2][e] = __builtin_bit_cast(__bf16, l[e]);
+        }
+    }
+}
+// FC1 operand of a tile: the lane's eight slots of sample j of tile c, three terms (24 halfword reads)
+struct Fc1In {
+    bf16x8 b[3];
+};
+DEV void load_fc1_in(Fc1In &o, const char *ser_b, const int (&hoff)[8], int c) {
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            o.b[pl][e] = __builtin_bit_cast(__bf16, *reinterpret_cast<const unsigned short *>(ser_b + 4 * BF_W + 2 * pl * BF_PLANE + hoff[e] + 32 * c));
+}
+DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+// a0, a1 = W1 (rows 0..15 | 16..31) x features, to fp32 accuracy: per row tile two chains of three products
+DEV void fc1_tile(f32x4 &a0, f32x4 &a1, const Fc1Weights &w, const Fc1In &x) {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 l0 = z, h0 = z, l1 = z, h1 = z;
+    const int ta[3] = {1, 2, 0}, tb[3] = {1, 0, 2};      // (weight term, feature term): mm, lh, hl  |  mh, hm, hh
+    const int ua[3] = {1, 0, 0}, ub[3] = {0, 1, 0};
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        l0 = mfma_bf(w.a[0][ta[k]], x.b[tb[k]], l0);
+        l1 = mfma_bf(w.a[1][ta[k]], x.b[tb[k]], l1);
+        h0 = mfma_bf(w.a[0][ua[k]], x.b[ub[k]], h0);
+        h1 = mfma_bf(w.a[1][ua[k]], x.b[ub[k]], h1);
+    }
+    a0 = h0 + l0;
+    a1 = h1 + l1;
 }
 struct FwdWeights {
     float A1[2][8];   // W1 tile t, step s: lane (i, g) holds W1[16t + i][slot 4s + g]
@@ -446,13 +552,22 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
                                                              const float2 *__restrict__ grad_out,
                                                              const float2 *__restrict__ target, float mse_scale,
                                                              float *__restrict__ slab, unsigned *__restrict__ queue) {
-    __shared__ __attribute__((aligned(16))) float lds[WAVES][BWD_WORDS];
+#if GEN_FC1_BF16
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // WAVES x BWD_WORDS (above the static limit)
+#else
+    __shared__ __attribute__((aligned(16))) float lds[WAVES * BWD_WORDS];   // static: addresses fold into the instructions
+#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
-    float *ser = lds[wave];
+    float *ser = lds + wave * BWD_WORDS;
     ser[ZERO_W + lane] = 0.f;
     ser[ONE_W + lane] = 1.f;
     FwdWeights w;
     load_fwd_weights(w, wq, j, g);
+#if GEN_FC1_BF16
+    init_planes(ser, lane);
+    Fc1Weights w1;
+    load_fc1_weights(w1, wq, j, g);
+#endif
     float A2T[2][4];  // W2[4g + r][16t + i]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -467,12 +582,21 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         w3r[1][r] = w3p[r][1];
     }
     const float b3k = wq[G_B3 + (g & 1)];
+#if GEN_FC1_BF16
+    int hoff[8];      // byte offsets inside a bf16 plane of the lane's eight FC1 slots, sample j
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int slot = 8 * g + e;
+        hoff[e] = 2 * (slot_half(slot) + (slot < 30 ? j : 0));
+    }
+#else
     int boff[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         int slot = 4 * s + g;
         boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
+#endif
     // dW1 A operand: lane (i = j, g) reads slot 16u + i of sample 4q + g
     int aoff[2];
 #pragma unroll
@@ -521,19 +645,28 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, gz2, e0, e1;
     };
     // FC1 operands are fetched from LDS one stage before the MFMAs that use them
-    auto F1 = [&](float (&b)[8], int c) {
-#pragma unroll
-        for (int s = 0; s < 8; ++s) b[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
+#if GEN_FC1_BF16
+    typedef Fc1In Fc1Operand;
+    auto F1 = [&](Fc1In &b, int c) { load_fc1_in(b, ser_b, hoff, c); };
+    auto S1 = [&](f32x4 &a0, f32x4 &a1, const Fc1In &b) { fc1_tile(a0, a1, w1, b); };   // b1 enters through slot 30
+#else
+    struct Fc1Operand {
+        float v[8];
     };
-    auto S1 = [&](f32x4 &a0, f32x4 &a1, const float (&b)[8]) {
+    auto F1 = [&](Fc1Operand &b, int c) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) b.v[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
+    };
+    auto S1 = [&](f32x4 &a0, f32x4 &a1, const Fc1Operand &b) {
         a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
         a1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            a0 = mfma4(w.A1[0][s], b[s], a0);
-            a1 = mfma4(w.A1[1][s], b[s], a1);
+            a0 = mfma4(w.A1[0][s], b.v[s], a0);
+            a1 = mfma4(w.A1[1][s], b.v[s], a1);
         }
     };
+#endif
     auto V1 = [&](Tile &t, int buf) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -757,7 +890,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #endif
             const int cA = 2 * p, cB = 2 * p + 1;
             Tile A, B;
-            float bA[8], bB[8];
+            Fc1Operand bA, bB;
             F1(bA, cA);
             F1(bB, cB);
             PHASE();
@@ -804,7 +937,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // ---- partial gradient row of this wave -> LDS, the workgroup's four rows are summed, one row per
     // workgroup goes to the slab (the staging regions are dead: every wave has left its loop)
     __syncthreads();
-    float *comb = &lds[0][0];
+    float *comb = lds;
     float *rowp = comb + wave * G_SLAB;
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -918,7 +1051,15 @@ int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *t
     const bool mse = grad_out == nullptr;
     const float mse_scale = mse ? (float)(2.0 / (2.0 * (double)p.N)) : 0.f;
     const float2 *go = reinterpret_cast<const float2 *>(grad_out), *tg = reinterpret_cast<const float2 *>(target);
-#define GO(Q, M) hipLaunchKernelGGL((k_gen_bwd_mfma<Q, M>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
+    static bool lds_allowed = !GEN_FC1_BF16;
+    if (!lds_allowed) {
+        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_bwd_mfma<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
+        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_bwd_mfma<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
+        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_bwd_mfma<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
+        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_bwd_mfma<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
+        lds_allowed = true;
+    }
+#define GO(Q, M) hipLaunchKernelGGL((k_gen_bwd_mfma<Q, M>), grid, block, GEN_FC1_BF16 ? BWD_LDS_BYTES : 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
                                     p.slope, p.absmax, go, tg, mse_scale, slab, queue)
     if (p.qat) { if (mse) GO(true, true); else GO(true, false); }
     else       { if (mse) GO(false, true); else GO(false, false); }
