@@ -923,6 +923,8 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
                                                                 const float *__restrict__ gscore, float gconst,
                                                                 float2 *__restrict__ gx, float *__restrict__ slab,
                                                                 float *__restrict__ score_sum, unsigned *__restrict__ queue) {
+    // (a static array above 64 KiB compiles and would save ~20 address additions per tile, but a launch with
+    // it never finished on the device: dynamic it stays)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // WGRAD: LDS_WORDS (> 64 KiB), else IMG_WORDS
     build_image(lds, wb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
