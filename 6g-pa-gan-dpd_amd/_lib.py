@@ -28,6 +28,7 @@ PROTOTYPES = {
     "dpd_gen_forward": [c_p, c_l, c_l, c_i, c_p, c_f, c_i, c_p, c_p, c_i, c_p],
     "dpd_gen_backward": [c_p, c_l, c_l, c_i, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_p],
     "dpd_gen_mse_step": [c_p, c_l, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_sz, c_i, c_p],
+    "dpd_gen_mse_step_noalloc": [c_p, c_l, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_p],
     "dpd_pa_forward": [c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_p, c_p],
     "dpd_pa_backward": [c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "dpd_quant_pa_forward": [c_p, c_l, c_l, c_p, c_p, c_p, c_i, c_i, c_p, c_p],

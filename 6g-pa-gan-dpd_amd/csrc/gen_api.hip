@@ -1,4 +1,5 @@
 // C ABI of the generator path: argument checks, kernel-family dispatch, multi-pass QAT driver.
+#include <mutex>
 #include "gen_internal.h"
 
 int gen_launch_prepare(const float *, const float *, const float *, const float *, const float *, const float *, int,
@@ -8,6 +9,9 @@ int gen_launch_quantize_output(float *, int64_t, const float *, hipStream_t);
 
 namespace {
 
+// what the generator backward uses of a workspace: 1024 slab rows (neither kernel family launches more
+// workgroups) and, right behind them, the chunk counter of the MFMA family
+constexpr size_t GEN_WS_BYTES = ((size_t)1024 * G_SLAB + 64) * sizeof(float);
 constexpr int64_t MFMA_MIN_SAMPLES = 4096;  // below this the VALU kernels win on launch geometry
 
 int make_problem(GenProblem &p, const float *x, int64_t B, int64_t S, int pre, const float *wq, float slope, int qat,
@@ -95,8 +99,8 @@ extern "C" int dpd_gen_forward(const float *x, int64_t B, int64_t S, int pre_ass
 static int backward_common(const GenProblem &p, const float *grad_out, const float *target, float *grads, float *loss,
                            float *grad_feat, void *ws, size_t ws_bytes, int impl, hipStream_t st) {
     DPD_REQUIRE(grads, DPD_ERR_INVALID_ARG, "gen_backward: grads is null");
-    DPD_REQUIRE(ws && ws_bytes >= dpd_workspace_bytes(0), DPD_ERR_WORKSPACE,
-                "gen_backward: workspace of %zu bytes needed, %zu given", dpd_workspace_bytes(0), ws_bytes);
+    DPD_REQUIRE(ws && ws_bytes >= GEN_WS_BYTES, DPD_ERR_WORKSPACE,
+                "gen_backward: workspace of %zu bytes needed, %zu given", GEN_WS_BYTES, ws_bytes);
     if (p.N == 0) {
         DPD_HIP(hipMemsetAsync(grads, 0, G_NP * sizeof(float), st));
         if (loss) DPD_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
@@ -133,6 +137,54 @@ extern "C" int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const flo
     if (rc) return rc;
     DPD_REQUIRE((target || B == 0) && loss, DPD_ERR_INVALID_ARG, "gen_mse_step: null target or loss");
     return backward_common(p, nullptr, target, grads, loss, nullptr, ws, ws_bytes, impl, as_stream(stream));
+}
+
+// ---- Stage-1 step for callers that cannot allocate ---------------------------------------------
+// Same kernels as dpd_gen_mse_step; the partial-gradient slab and the chunk counter live in a
+// file-scope device array instead of a caller-provided workspace.  Every GPU holds its own copy of the
+// array at its own address: the address is looked up once per device and kept.
+constexpr size_t NOALLOC_FLOATS = (size_t)1024 * G_SLAB + 64;        // 1024 slab rows + the chunk counter behind them
+static_assert(NOALLOC_FLOATS * sizeof(float) == GEN_WS_BYTES, "scratch covers exactly what the backward uses");
+static __device__ __align__(256) float scratch[NOALLOC_FLOATS];      // 6,390,016 bytes per GPU, held until the process ends
+
+namespace {
+constexpr int MAX_DEVICES = 64;
+float *g_scratch_ptr[MAX_DEVICES];     // device address of `scratch` on each GPU (0 = not looked up yet)
+std::mutex g_scratch_mutex;
+
+int scratch_of_current_device(float **ptr) {
+    int dev = -1;
+    DPD_HIP(hipGetDevice(&dev));
+    DPD_REQUIRE(dev >= 0 && dev < MAX_DEVICES, DPD_ERR_INVALID_ARG, "gen_mse_step_noalloc: device index %d not in 0..%d", dev, MAX_DEVICES - 1);
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (g_scratch_ptr[dev] == nullptr) {
+        void *p = nullptr;
+        DPD_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        DPD_REQUIRE(p != nullptr, DPD_ERR_HIP, "gen_mse_step_noalloc: the scratch array has no address on device %d", dev);
+        g_scratch_ptr[dev] = static_cast<float *>(p);
+    }
+    *ptr = g_scratch_ptr[dev];
+    return DPD_OK;
+}
+}  // namespace
+
+extern "C" int dpd_gen_mse_step_noalloc(const float *iq, int64_t B, int64_t S, const float *target, const float *wq,
+                                        float slope, int qat, const float *absmax, float *grads, float *loss,
+                                        int impl, void *stream) {
+    GenProblem p;
+    int rc = make_problem(p, iq, B, S, 0, wq, slope, qat, const_cast<float *>(absmax));
+    if (rc) return rc;
+    DPD_REQUIRE((target || B == 0) && loss, DPD_ERR_INVALID_ARG, "gen_mse_step_noalloc: null target or loss");
+    DPD_REQUIRE(p.N <= DPD_NOALLOC_MAX_SAMPLES, DPD_ERR_WORKSPACE,
+                "gen_mse_step_noalloc: %lld samples exceed the maximum of %lld per call; split the batch or use dpd_gen_mse_step",
+                (long long)p.N, (long long)DPD_NOALLOC_MAX_SAMPLES);
+    float *ptr = nullptr;
+    rc = scratch_of_current_device(&ptr);
+    if (rc) return rc;
+    // the slab rows a launch reads are all written by that launch, and the chunk counter is cleared by the
+    // backward launcher on `stream`: nothing of an earlier call's contents is used
+    return backward_common(p, nullptr, target, grads, loss, nullptr, ptr, NOALLOC_FLOATS * sizeof(float), impl,
+                           as_stream(stream));
 }
 
 // Chain iq -> generator -> PA twin with the generator's scales already known (QAT: absmax[0..3] filled

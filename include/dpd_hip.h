@@ -112,6 +112,18 @@ int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const float *target,
                      int qat, const float *absmax, float *grads, float *loss,
                      void *ws, size_t ws_bytes, int impl, void *stream);
 
+/* dpd_gen_mse_step for callers that cannot allocate device memory (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same
+ * arguments minus the workspace: the partial-gradient slab and the chunk counter live in a device array
+ * inside the library (6,390,016 bytes per GPU, held until the process ends), so the call makes no
+ * allocation of any kind.  At most DPD_NOALLOC_MAX_SAMPLES = B * (S - 5) samples per call
+ * (DPD_ERR_WORKSPACE above that).  All calls on one GPU share that GPU's array: calls that overlap on one
+ * GPU (different streams or threads) race; calls on one stream are ordered and need nothing cleared. */
+#define DPD_NOALLOC_MAX_SAMPLES ((int64_t)1 << 30)
+int dpd_gen_mse_step_noalloc(const float *iq, int64_t B, int64_t S, const float *target, const float *wq,
+                             float slope, int qat, const float *absmax, float *grads, float *loss, int impl,
+                             void *stream);
+
 /* ---------------------------------------------------------------- PA twin --------------- */
 
 /* VolterraPA.forward (models/pa_digital_twin.py:125-170): x [B,S,2] -> y [B,S-M+1,2] with
