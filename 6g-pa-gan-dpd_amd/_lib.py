@@ -33,6 +33,8 @@ PROTOTYPES = {
     "dpd_pa_backward": [c_p, c_l, c_l, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "dpd_quant_pa_forward": [c_p, c_l, c_l, c_p, c_p, c_p, c_i, c_i, c_p, c_p],
     "dpd_gen_pa_forward": [c_p, c_l, c_l, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
+    "dpd_gen_pa_backward": [c_p, c_l, c_l, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_sz, c_p],
+    "dpd_gen_pa_mse_step": [c_p, c_l, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_sz, c_p],
     "dpd_critic_sn_forward": [c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p],
     "dpd_critic_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p],
     "dpd_critic_forward": [c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p],
@@ -44,6 +46,8 @@ PROTOTYPES = {
     "dpd_spectral_loss_final": [c_p, c_l, c_f, c_f, c_f, c_p, c_p],
     "dpd_spectral_terms_backward": [c_p, c_p, c_p, c_l, c_l, c_p, c_p],
     "dpd_quantize_fixed": [c_p, c_l, c_f, c_i, c_i, c_i, c_p, c_p],
+    "dpd_quantized_linear": [c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_i, c_i, c_f, c_i, c_i, c_p, c_p],
+    "dpd_quantized_linear_backward": [c_p, c_p, c_p, c_l, c_i, c_i, c_f, c_i, c_i, c_f, c_i, c_i, c_p, c_p, c_p, c_p],
     "dpd_fake_quantize_dynamic": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p],
     "dpd_q88_infer": [c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "dpd_q88_int32_safe": [c_p, c_p, c_p, c_p, c_p, c_p],

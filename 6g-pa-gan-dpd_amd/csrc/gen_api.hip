@@ -97,7 +97,8 @@ extern "C" int dpd_gen_forward(const float *x, int64_t B, int64_t S, int pre_ass
 }
 
 static int backward_common(const GenProblem &p, const float *grad_out, const float *target, float *grads, float *loss,
-                           float *grad_feat, void *ws, size_t ws_bytes, int impl, hipStream_t st) {
+                           float *grad_feat, void *ws, size_t ws_bytes, int impl, hipStream_t st,
+                           const GenPaChain *chain = nullptr) {
     DPD_REQUIRE(grads, DPD_ERR_INVALID_ARG, "gen_backward: grads is null");
     DPD_REQUIRE(ws && ws_bytes >= GEN_WS_BYTES, DPD_ERR_WORKSPACE,
                 "gen_backward: workspace of %zu bytes needed, %zu given", GEN_WS_BYTES, ws_bytes);
@@ -110,12 +111,15 @@ static int backward_common(const GenProblem &p, const float *grad_out, const flo
     int n_partials = 0, rc;
     if (use_mfma(p, impl)) {
         DPD_REQUIRE(grad_feat == nullptr, DPD_ERR_INVALID_ARG, "gen_backward: grad_feat needs pre-assembled input");
-        rc = gen_mfma_backward(p, grad_out, target, slab, &n_partials, st);
+        rc = gen_mfma_backward(p, grad_out, target, slab, &n_partials, st, chain);
     } else {
+        DPD_REQUIRE(chain == nullptr, DPD_ERR_INVALID_ARG, "gen_backward: the fused chain runs on the MFMA kernels only");
         rc = gen_valu_backward(p, grad_out, target, grad_feat, slab, &n_partials, st);
     }
     if (rc) return rc;
-    return gen_reduce_slab(slab, n_partials, grads, loss, 1.0f / (2.0f * (float)p.N), st);
+    // the slab's loss column holds sums of squared differences: mean over the elements of the compared tensor
+    const double n_elem = 2.0 * (double)p.B * (double)(chain ? p.L - (chain->M - 1) : p.L);
+    return gen_reduce_slab(slab, n_partials, grads, loss, (float)(1.0 / n_elem), st);
 }
 
 extern "C" int dpd_gen_backward(const float *x, int64_t B, int64_t S, int pre_assembled, const float *wq, float slope,
@@ -137,6 +141,71 @@ extern "C" int dpd_gen_mse_step(const float *iq, int64_t B, int64_t S, const flo
     if (rc) return rc;
     DPD_REQUIRE((target || B == 0) && loss, DPD_ERR_INVALID_ARG, "gen_mse_step: null target or loss");
     return backward_common(p, nullptr, target, grads, loss, nullptr, ws, ws_bytes, impl, as_stream(stream));
+}
+
+// ---- chain generator -> PA twin with its backward -------------------------------------------------
+int pa_launch_mse_grad(const float *y, const float *t, int64_t n, float *gy, double *part, float *loss, hipStream_t st);
+
+namespace {
+// One kernel when the batch is large enough for the MFMA family and the PA has the reference's shape
+// (5 taps, at most 4 odd orders).  Otherwise the same result from the separate kernels, with the generator
+// output, the PA output / its gradient and the gradient w.r.t. the generator output in the tail of the workspace.
+int chain_backward(const GenProblem &p, const float *cre, const float *cim, int K, int M, const float *gy,
+                   const float *target, float *grads, float *loss, void *ws, size_t ws_bytes, hipStream_t st) {
+    DPD_REQUIRE(cre && cim, DPD_ERR_INVALID_ARG, "gen_pa: null coefficient pointer");
+    DPD_REQUIRE(K >= 1 && K <= 8 && M >= 1 && M <= 16, DPD_ERR_INVALID_ARG, "gen_pa: K in 1..8, M in 1..16");
+    DPD_REQUIRE(p.L >= M, DPD_ERR_SHAPE, "Sequence length %lld must be >= memory depth %d", (long long)p.L, M);
+    DPD_REQUIRE(grads, DPD_ERR_INVALID_ARG, "gen_pa: grads is null");
+    if (p.N == 0) {
+        DPD_HIP(hipMemsetAsync(grads, 0, G_NP * sizeof(float), st));
+        if (loss) DPD_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+        return DPD_OK;
+    }
+    const GenPaChain chain{cre, cim, K, M};
+    if (use_mfma(p, DPD_IMPL_AUTO) && M == 5 && K <= 4)
+        return backward_common(p, gy, target, grads, loss, nullptr, ws, ws_bytes, DPD_IMPL_MFMA, st, &chain);
+    const int64_t OL = p.L - M + 1, NY = p.B * OL;
+    DPD_REQUIRE(ws && ws_bytes >= dpd_workspace_bytes(p.N), DPD_ERR_WORKSPACE,
+                "gen_pa: this shape runs on the separate kernels and needs a workspace of %zu bytes, %zu given",
+                dpd_workspace_bytes(p.N), ws_bytes);
+    char *tail = static_cast<char *>(ws) + dpd_workspace_bytes(0);
+    double *part = reinterpret_cast<double *>(tail - 8192);                // inside the spare megabyte behind the slabs
+    float *dpd = reinterpret_cast<float *>(tail);                           // [B, L, 2]
+    float *yb = dpd + 2 * p.N;                                              // [B, OL, 2]: PA output, then its gradient
+    float *gx = yb + 2 * p.N;                                               // [B, L, 2]
+    int rc = forward_dispatch(p, p.qat ? 3 : 4, dpd, DPD_IMPL_AUTO, st);    // (pass 3 rewrites absmax[3] with the value it holds)
+    if (!rc && p.qat) rc = gen_launch_quantize_output(dpd, p.N * 2, p.absmax, st);
+    if (!rc) rc = dpd_pa_forward(dpd, p.B, p.L, cre, cim, K, M, yb, st);
+    const float *gyp = gy;
+    if (!rc && target) {
+        rc = pa_launch_mse_grad(yb, target, 2 * NY, yb, part, loss, st);
+        gyp = yb;
+    }
+    if (!rc) rc = dpd_pa_backward(dpd, p.B, p.L, cre, cim, K, M, gyp, gx, st);
+    if (rc) return rc;
+    return backward_common(p, gx, nullptr, grads, nullptr, nullptr, ws, ws_bytes, DPD_IMPL_AUTO, st);
+}
+}  // namespace
+
+extern "C" int dpd_gen_pa_backward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
+                                   const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
+                                   const float *gy, float *grads, void *ws, size_t ws_bytes, void *stream) {
+    GenProblem p;
+    int rc = make_problem(p, iq, B, S, 0, wq, slope, qat, const_cast<float *>(absmax));
+    if (rc) return rc;
+    DPD_REQUIRE(gy || B == 0, DPD_ERR_INVALID_ARG, "gen_pa_backward: gy is null");
+    return chain_backward(p, coef_re, coef_im, K, M, gy, nullptr, grads, nullptr, ws, ws_bytes, as_stream(stream));
+}
+
+extern "C" int dpd_gen_pa_mse_step(const float *iq, int64_t B, int64_t S, const float *target, const float *wq,
+                                   float slope, int qat, const float *absmax, const float *coef_re,
+                                   const float *coef_im, int K, int M, float *grads, float *loss, void *ws,
+                                   size_t ws_bytes, void *stream) {
+    GenProblem p;
+    int rc = make_problem(p, iq, B, S, 0, wq, slope, qat, const_cast<float *>(absmax));
+    if (rc) return rc;
+    DPD_REQUIRE((target || B == 0) && loss, DPD_ERR_INVALID_ARG, "gen_pa_mse_step: null target or loss");
+    return chain_backward(p, coef_re, coef_im, K, M, nullptr, target, grads, loss, ws, ws_bytes, as_stream(stream));
 }
 
 // ---- Stage-1 step for callers that cannot allocate ---------------------------------------------

@@ -24,8 +24,13 @@ int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st)
 // one kernel: generator forward (final scales in p.absmax when p.qat) + memory-polynomial PA; out may be NULL
 int gen_mfma_pa_forward(const GenProblem &p, const float *cre, const float *cim, int K, int M, float *out, float *y,
                         hipStream_t st);
+// chain != NULL: the loss / upstream gradient lives on the PA output [B, L - 4, 2] (generator -> PA twin, fused)
+struct GenPaChain {
+    const float *cre, *cim;   // [K, M]
+    int K, M;
+};
 int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *target,
-                      float *slab, int *n_partials, hipStream_t st);
+                      float *slab, int *n_partials, hipStream_t st, const GenPaChain *chain = nullptr);
 
 // grads[1554] (+ loss) = sum over n_partials slab rows (double accumulation, deterministic order)
 int gen_reduce_slab(const float *slab, int n_partials, float *grads, float *loss, float loss_scale, hipStream_t st);

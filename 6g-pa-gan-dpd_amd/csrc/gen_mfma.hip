@@ -39,30 +39,17 @@ constexpr int ZERO_W = 360;         // 64 words that always hold 0: operand of t
 constexpr int ONE_W = 424;          // 64 words that always hold 1: slot 30 is the bias input (its W1 column is b1,
                                     // its dW1 row is the bias gradient)
 constexpr int TG_W = 488;           // 64 x float2: the chunk's target / upstream gradient, sample-major (backward only)
-// Experiment, off by default (-DGEN_FC1_BF16=1): FC1 of the fused backward kernel on the bf16 matrix cores
-// with both operands split three ways into bf16 (x = hi + mid + lo to 24 bits, six products, fp32
-// accumulation: the accuracy of the fp32 MFMA with 12 MFMAs of 8 ns instead of 16 of 14.5 ns).  The series
-// are then also staged as bf16 terms: three planes (hi, mid, lo) of seven rows of 72 halfwords: the five
-// series, a row of ones (slot 30; zero in the mid and lo planes) and a row of zeros (slot 31).  Parity
-// holds, but the kernel is 7 % slower (1.18 ms against 1.10 ms): 24 halfword reads and 12 packing
-// instructions per tile instead of 8 word reads, plus the splits at staging time, cost more than the MFMAs
-// save; it would take ds_read_u16_d16(_hi) loads and fewer staged terms to turn this around.
-#ifndef GEN_FC1_BF16
-#define GEN_FC1_BF16 0
-#endif
-constexpr int BF_W = 616;           // word offset of the bf16 planes
-constexpr int BF_ROW = 72;          // halfwords per row
-constexpr int BF_PLANE = 7 * BF_ROW;   // halfwords per plane
-constexpr int SER_WORDS = GEN_FC1_BF16 ? BF_W + 3 * BF_PLANE / 2 : BF_W;   // 1372 | 616
+constexpr int PAC_W = 616;          // 48 words: memory-polynomial coefficients [tap 0..5][re k0..3 | im k0..3] (tap 5: zeros), fused chain backward
+constexpr int SER_WORDS = PAC_W + 48;   // 664
 constexpr int P32 = 48;             // row pitch of the transposition tiles (16 mod 32)
 // backward: two tile buffers per wave (two tiles are in flight), each = [16 samples][gz1 (32) | gz2 (16)] and
 // [16 samples][h1 (32) | unused (16)], both with the 48-word pitch and the XOR swizzle of swz()
 constexpr int TILE_W = 2 * 16 * P32;             // words per tile buffer (1536)
 constexpr int GZ_W = SER_WORDS;                  // + TILE_W * buffer
 constexpr int H1_W = GZ_W + 16 * P32;
-constexpr int BWD_WORDS = SER_WORDS + 2 * TILE_W;   // 3688 words per wave
+constexpr int BWD_WORDS = SER_WORDS + 2 * TILE_W;   // 3736 words per wave
 static_assert(WAVES * BWD_WORDS >= WAVES * G_SLAB, "the gradient rows are combined in the staging LDS");
-constexpr size_t BWD_LDS_BYTES = (size_t)WAVES * BWD_WORDS * sizeof(float);   // 58 KiB (71 KiB with the bf16 planes): dynamic LDS, two workgroups per CU
+static_assert((size_t)WAVES * BWD_WORDS * sizeof(float) <= 65536, "static LDS of the backward kernel: 58.4 KiB, two workgroups per CU");
 
 DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -81,26 +68,6 @@ DEV int slot_word(int slot) {
     return SER_BASE0 + SER_STRIDE * type + 5 - tap;
 }
 DEV int swz(int s) { return 4 * ((s >> 1) & 3); }
-// halfword offset inside a bf16 plane of (slot, sample 0 of tile 0); add sample index and 16 * tile
-DEV int slot_half(int slot) {
-    if (slot >= 30) return (slot == 30 ? 5 : 6) * BF_ROW;
-    int type = slot / 6, tap = slot - 6 * type;
-    return type * BF_ROW + 5 - tap;
-}
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-// x = h + m + l to 24 bits as bf16 bit patterns: h and m by truncation (the masked value is the term as a
-// float, the subtraction is exact), l by rounding
-DEV void split3(float x, unsigned short &h, unsigned short &m, unsigned short &l) {
-    const unsigned u = __builtin_bit_cast(unsigned, x);
-    h = (unsigned short)(u >> 16);
-    const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
-    const unsigned v = __builtin_bit_cast(unsigned, r1);
-    m = (unsigned short)(v >> 16);
-    const float r2 = r1 - __builtin_bit_cast(float, v & 0xffff0000u);
-    l = __builtin_bit_cast(unsigned short, (__bf16)r2);
-}
-
 struct Lane {
     int lane, j, g;
 };
@@ -141,80 +108,7 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
         p[2 * SER_STRIDE] = e;
         p[3 * SER_STRIDE] = e2;
         p[4 * SER_STRIDE] = e4;
-        if (GEN_FC1_BF16) {
-            unsigned short *bp = reinterpret_cast<unsigned short *>(ser + BF_W) + tau;
-            const float val[5] = {v.x, v.y, e, e2, e4};
-#pragma unroll
-            for (int type = 0; type < 5; ++type) {
-                unsigned short h, m, l;
-                split3(val[type], h, m, l);
-                bp[type * BF_ROW] = h;
-                bp[BF_PLANE + type * BF_ROW] = m;
-                bp[2 * BF_PLANE + type * BF_ROW] = l;
-            }
-        }
     }
-}
-// the constant rows of the bf16 planes (once per wave)
-DEV void init_planes(float *ser, int lane) {
-    unsigned short *bp = reinterpret_cast<unsigned short *>(ser + BF_W);
-    for (int k = lane; k < BF_ROW; k += 64) {
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            bp[pl * BF_PLANE + 5 * BF_ROW + k] = pl == 0 ? (unsigned short)0x3f80 : (unsigned short)0;   // 1.0
-            bp[pl * BF_PLANE + 6 * BF_ROW + k] = 0;
-        }
-    }
-}
-// FC1 operands of a lane: W1 rows 16t + i over the eight slots 8g + e, three terms each
-struct Fc1Weights {
-    bf16x8 a[2][3];
-};
-DEV void load_fc1_weights(Fc1Weights &w, const float *__restrict__ wq, int j, int g) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        unsigned short h[8], m[8], l[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int slot = 8 * g + e, ref = slot_ref(slot);
-            const float x = ref >= 0 ? wq[G_W1 + (16 * t + j) * 30 + ref] : (slot == 30 ? wq[G_B1 + 16 * t + j] : 0.f);
-            split3(x, h[e], m[e], l[e]);
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            w.a[t][0][e] = __builtin_bit_cast(__bf16, h[e]);
-            w.a[t][1][e] = __builtin_bit_cast(__bf16, m[e]);
-            w.a[t][2][e] = __builtin_bit_cast(__bf16, l[e]);
-        }
-    }
-}
-// FC1 operand of a tile: the lane's eight slots of sample j of tile c, three terms (24 halfword reads)
-struct Fc1In {
-    bf16x8 b[3];
-};
-DEV void load_fc1_in(Fc1In &o, const char *ser_b, const int (&hoff)[8], int c) {
-#pragma unroll
-    for (int pl = 0; pl < 3; ++pl)
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-            o.b[pl][e] = __builtin_bit_cast(__bf16, *reinterpret_cast<const unsigned short *>(ser_b + 4 * BF_W + 2 * pl * BF_PLANE + hoff[e] + 32 * c));
-}
-DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
-// a0, a1 = W1 (rows 0..15 | 16..31) x features, to fp32 accuracy: per row tile two chains of three products
-DEV void fc1_tile(f32x4 &a0, f32x4 &a1, const Fc1Weights &w, const Fc1In &x) {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    f32x4 l0 = z, h0 = z, l1 = z, h1 = z;
-    const int ta[3] = {1, 2, 0}, tb[3] = {1, 0, 2};      // (weight term, feature term): mm, lh, hl  |  mh, hm, hh
-    const int ua[3] = {1, 0, 0}, ub[3] = {0, 1, 0};
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        l0 = mfma_bf(w.a[0][ta[k]], x.b[tb[k]], l0);
-        l1 = mfma_bf(w.a[1][ta[k]], x.b[tb[k]], l1);
-        h0 = mfma_bf(w.a[0][ua[k]], x.b[ub[k]], h0);
-        h1 = mfma_bf(w.a[1][ua[k]], x.b[ub[k]], h1);
-    }
-    a0 = h0 + l0;
-    a1 = h1 + l1;
 }
 struct FwdWeights {
     float A1[2][8];   // W1 tile t, step s: lane (i, g) holds W1[16t + i][slot 4s + g]
@@ -578,30 +472,41 @@ __global__ __launch_bounds__(256) void k_iq_absmax(const float4 *__restrict__ iq
 }
 
 // ------------------------------------------------------------------------------------ backward
-template <bool QAT, bool MSE>
+// PA: the chain generator -> (output quantiser) -> memory-polynomial PA twin with its backward in the same
+// kernel (K <= 4 odd orders, M = 5 taps: the reference's PA).  The loss or upstream gradient then lives on
+// the PA output [B, OL = L - 4, 2].  The unit of the chain is the tile PAIR, whose two tiles are in registers
+// together in the output stage anyway: its 32 generator outputs give 28 PA outputs, whose gradient goes back
+// to those 32 generator outputs; pairs (and chunks) overlap by 4 generator outputs.  A generator output
+// in an overlap is run through the backward in both pairs, each with the part of its gradient that comes
+// from that pair's own PA outputs: everything downstream of that gradient is linear in it, so the two
+// parts add up to the whole.  A chunk therefore advances by 56 PA outputs (pairs at 0 and 28).
+struct PaBwdArgs {
+    const float *cre, *cim;   // [K, 5]
+    int K;
+    int64_t OL;               // PA outputs per row
+};
+constexpr int PA_M = 5, PA_PAIR = 32 - (PA_M - 1), PA_CHUNK = 2 * PA_PAIR;
+template <bool QAT, bool MSE, bool PA>
 __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
                                                              int64_t cpr, int64_t n_chunks,
                                                              const float *__restrict__ wq, float slope,
                                                              const float *__restrict__ absmax,
                                                              const float2 *__restrict__ grad_out,
                                                              const float2 *__restrict__ target, float mse_scale,
-                                                             float *__restrict__ slab, unsigned *__restrict__ queue) {
-#if GEN_FC1_BF16
-    extern __shared__ __attribute__((aligned(16))) float lds[];   // WAVES x BWD_WORDS (above the static limit)
-#else
+                                                             float *__restrict__ slab, unsigned *__restrict__ queue,
+                                                             PaBwdArgs pa) {
     __shared__ __attribute__((aligned(16))) float lds[WAVES * BWD_WORDS];   // static: addresses fold into the instructions
-#endif
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     float *ser = lds + wave * BWD_WORDS;
     ser[ZERO_W + lane] = 0.f;
     ser[ONE_W + lane] = 1.f;
+    if (PA && lane < 48) {   // coefficient block of this wave: [tap][re k0..3 | im k0..3], orders >= K and tap 5 are zero
+        const int m = lane >> 3, k = lane & 3;
+        const float *src = (lane & 4) ? pa.cim : pa.cre;
+        ser[PAC_W + lane] = (m < PA_M && k < pa.K) ? src[k * PA_M + m] : 0.f;
+    }
     FwdWeights w;
     load_fwd_weights(w, wq, j, g);
-#if GEN_FC1_BF16
-    init_planes(ser, lane);
-    Fc1Weights w1;
-    load_fc1_weights(w1, wq, j, g);
-#endif
     float A2T[2][4];  // W2[4g + r][16t + i]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -616,21 +521,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         w3r[1][r] = w3p[r][1];
     }
     const float b3k = wq[G_B3 + (g & 1)];
-#if GEN_FC1_BF16
-    int hoff[8];      // byte offsets inside a bf16 plane of the lane's eight FC1 slots, sample j
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        int slot = 8 * g + e;
-        hoff[e] = 2 * (slot_half(slot) + (slot < 30 ? j : 0));
-    }
-#else
     int boff[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         int slot = 4 * s + g;
         boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
-#endif
     // dW1 A operand: lane (i = j, g) reads slot 16u + i of sample 4q + g
     int aoff[2];
 #pragma unroll
@@ -678,18 +574,15 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     struct Tile {
         f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, gz2, e0, e1;
     };
-    // FC1 operands are fetched from LDS one stage before the MFMAs that use them
-#if GEN_FC1_BF16
-    typedef Fc1In Fc1Operand;
-    auto F1 = [&](Fc1In &b, int c) { load_fc1_in(b, ser_b, hoff, c); };
-    auto S1 = [&](f32x4 &a0, f32x4 &a1, const Fc1In &b) { fc1_tile(a0, a1, w1, b); };   // b1 enters through slot 30
-#else
+    // FC1 operands are fetched from LDS one stage before the MFMAs that use them.  A tile is named by the
+    // byte offset of its first sample inside the chunk's series (64 * tile, or 4 * (28 * pair + 16 * half) in
+    // the chain, whose pairs overlap)
     struct Fc1Operand {
         float v[8];
     };
-    auto F1 = [&](Fc1Operand &b, int c) {
+    auto F1 = [&](Fc1Operand &b, int toff) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) b.v[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
+        for (int s = 0; s < 8; ++s) b.v[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + toff);
     };
     auto S1 = [&](f32x4 &a0, f32x4 &a1, const Fc1Operand &b) {
         a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
@@ -700,7 +593,6 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             a1 = mfma4(w.A1[1][s], b.v[s], a1);
         }
     };
-#endif
     auto V1 = [&](Tile &t, int buf) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -736,18 +628,101 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // then goes to all lane groups with three row swaps, where dW3 and gh2 = W3^T gz3 (two FMAs per
     // neuron) follow on the VALU.
     const int tg_off = 2 * (16 * (g >> 1) + j) + (g & 1);
+    // Chain: the pair's 32 generator outputs -> 28 PA outputs -> loss / upstream gradient -> gradient w.r.t. the
+    // 32 generator outputs, all inside the output stage.  With u = the (quantised) generator output of a sample,
+    // p = |u|^2 and P_m the tap polynomials, y[n] = sum_m u[n+4-m] P_m(p[n+4-m]) and, for G = dL/dy (real and
+    // imaginary part as a complex number), dL/du[t] = sum_m G[t-4+m] conj(P_m(p_t)) + 2 u_t sum_m Re(conj(G[t-4+m]) u_t P_m'(p_t)).
+    // Lane (g, j) owns component c = g & 1 of sample tl = 16 (g >> 1) + j of the pair; the two lanes of a sample
+    // split the taps (c = 0: taps 0..2, c = 1: taps 3, 4 and an all-zero tap 5) and exchange three partial sums.
+    // Scratch: the gz tile buffer 0, which is dead between the pairs (LDS operations of a wave run in order).
+    auto pa_stage = [&](float y, int p, int64_t t0_cur) -> float {
+        const int c = g & 1, tl = 16 * (g >> 1) + j;
+        float *const fbuf = ser + GZ_W;          // [6 taps][32 samples] float2: u P_m(p)
+        float *const gbuf = ser + GZ_W + 384;    // [4 zeros | 28 G | 5 zeros] float2
+        const float o = QAT ? fq16(y, s3) : y;   // straight-through: the gradient passes the quantiser unchanged
+        const unsigned ob = __builtin_bit_cast(unsigned, o);
+        const auto sw = __builtin_amdgcn_permlane16_swap(ob, ob, false, false);   // (component 0, component 1) in every lane
+        unsigned u0 = sw[0], u1 = sw[1];
+        asm volatile("" : "+v"(u0), "+v"(u1));
+        const float ur = __builtin_bit_cast(float, u0), ui = __builtin_bit_cast(float, u1);
+        const float pw = ur * ur + ui * ui;
+        float Pr[3], Pi[3], Dr[3], Di[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int m = 3 * c + i;
+            const f32x4 cr = *reinterpret_cast<const f32x4 *>(ser + PAC_W + 8 * m);
+            const f32x4 ci = *reinterpret_cast<const f32x4 *>(ser + PAC_W + 8 * m + 4);
+            float pr = cr[3], pi = ci[3], dr = 0.f, di = 0.f;   // Horner with derivative in p
+#pragma unroll
+            for (int k = 2; k >= 0; --k) {
+                dr = __builtin_fmaf(dr, pw, pr);
+                di = __builtin_fmaf(di, pw, pi);
+                pr = __builtin_fmaf(pr, pw, cr[k]);
+                pi = __builtin_fmaf(pi, pw, ci[k]);
+            }
+            Pr[i] = pr; Pi[i] = pi; Dr[i] = dr; Di[i] = di;
+            const float2 f = make_float2(__builtin_fmaf(ur, pr, -(ui * pi)), __builtin_fmaf(ur, pi, ui * pr));
+            *reinterpret_cast<float2 *>(fbuf + 2 * (32 * m + tl)) = f;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // PA output n = tl of the pair, component c (n >= 28 has no full window here: computed on clamped taps, masked)
+        float yc = 0.f;
+#pragma unroll
+        for (int m = 0; m < PA_M; ++m) {
+            const int idx = min(tl + PA_M - 1 - m, 31);
+            yc += fbuf[2 * (32 * m + idx) + c];
+        }
+        const bool nvalid = tl < PA_PAIR && (t0_cur + PA_PAIR * p + tl) < pa.OL;
+        const float v = tg_f[2 * (PA_PAIR * p + tl) + c];
+        float G;
+        if (MSE) {
+            const float d = nvalid ? yc - v : 0.f;
+            loss = __builtin_fmaf(d, d, loss);
+            G = d * mse_scale;
+        } else {
+            G = nvalid ? v : 0.f;
+        }
+        gbuf[2 * (4 + tl) + c] = G;
+        if (tl < 5) gbuf[2 * (tl < 4 ? tl : 36) + c] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+        float ar = 0.f, ai = 0.f, b = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float2 Gm = *reinterpret_cast<const float2 *>(gbuf + 2 * (tl + 3 * c + i));   // G[tl - 4 + m]
+            ar = __builtin_fmaf(Gm.x, Pr[i], __builtin_fmaf(Gm.y, Pi[i], ar));
+            ai = __builtin_fmaf(Gm.y, Pr[i], __builtin_fmaf(-Gm.x, Pi[i], ai));
+            const float qr = __builtin_fmaf(ur, Dr[i], -(ui * Di[i])), qi = __builtin_fmaf(ur, Di[i], ui * Dr[i]);
+            b = __builtin_fmaf(Gm.x, qr, __builtin_fmaf(Gm.y, qi, b));
+        }
+        auto both = [&](float x) {   // sum over the two lanes of the sample
+            const unsigned xb = __builtin_bit_cast(unsigned, x);
+            const auto r = __builtin_amdgcn_permlane16_swap(xb, xb, false, false);
+            unsigned x0 = r[0], x1 = r[1];
+            asm volatile("" : "+v"(x0), "+v"(x1));
+            return __builtin_bit_cast(float, x0) + __builtin_bit_cast(float, x1);
+        };
+        ar = both(ar);
+        ai = both(ai);
+        b = both(b);
+        __builtin_amdgcn_wave_barrier();
+        return __builtin_fmaf(2.f * (c ? ui : ur), b, c ? ai : ar);
+    };
     auto V3P = [&](Tile &A, Tile &B, int p, int64_t t0_cur) {
         const float y = tanh_f32(fc3_pair(w3p, b3k, A.h2, B.h2));
-        const bool valid = (t0_cur + 32 * p + 16 * (g >> 1) + j) < L;
-        const float v = tg_f[tg_off + 64 * p];
         float gup;
-        if (MSE) {
-            const float o = QAT ? fq16(y, s3) : y;
-            const float d = valid ? o - v : 0.f;
-            loss = __builtin_fmaf(d, d, loss);
-            gup = d * mse_scale;
+        if constexpr (PA) {
+            gup = pa_stage(y, p, t0_cur);
         } else {
-            gup = v;                            // zero beyond L (never loaded)
+            const bool valid = (t0_cur + 32 * p + 16 * (g >> 1) + j) < L;
+            const float v = tg_f[tg_off + 64 * p];
+            if (MSE) {
+                const float o = QAT ? fq16(y, s3) : y;
+                const float d = valid ? o - v : 0.f;
+                loss = __builtin_fmaf(d, d, loss);
+                gup = d * mse_scale;
+            } else {
+                gup = v;                            // zero beyond L (never loaded)
+            }
         }
         const float gz3 = gup * (1.f - y * y);
         db3 += gz3;                             // lanes with g & 1 == k collect db3[k]
@@ -792,14 +767,14 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         *reinterpret_cast<f32x4 *>(gz_b + wr32) = t.e0;
         *reinterpret_cast<f32x4 *>(gz_b + wr32 + 64) = t.e1;
     };
-    auto S6 = [&](int c, int buf) {   // samples move from lanes to the MFMA K axis through the LDS tiles
+    auto S6 = [&](int toff, int buf) {   // samples move from lanes to the MFMA K axis through the LDS tiles
         const char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
         const char *h1_b = ser_b + 4 * (H1_W + TILE_W * buf);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             // samples 4q + g of this tile
-            float x0 = *reinterpret_cast<const float *>(ser_b + aoff[0] + 64 * c + 16 * q);
-            float x1 = *reinterpret_cast<const float *>(ser_b + aoff[1] + 64 * c + 16 * q);
+            float x0 = *reinterpret_cast<const float *>(ser_b + aoff[0] + toff + 16 * q);
+            float x1 = *reinterpret_cast<const float *>(ser_b + aoff[1] + toff + 16 * q);
             float gza = *reinterpret_cast<const float *>(gz_b + rd32[q]);
             float gzb = *reinterpret_cast<const float *>(gz_b + rd32[q] + 64);
             dW1[0][0] = mfma4(x0, gza, dW1[0][0]);
@@ -837,6 +812,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // The HBM reads of a chunk (69 IQ points, 64 targets or upstream gradients) are issued one chunk
     // ahead and parked in LDS at the top of the next iteration: no load latency inside the tile code.
     const float2 *gsrc = MSE ? target : grad_out;
+    constexpr int CSTEP = PA ? PA_CHUNK : CHUNK, PSTEP = PA ? PA_PAIR : 32;   // outputs a chunk / a pair advances by
+    const int64_t LT = PA ? pa.OL : L;                                        // row length of the target / upstream gradient
     // Units of UNIT consecutive chunks are handed out through a device counter (first come, first
     // served): waves on faster or earlier-started CUs take more units, none idles at the end.  The
     // counter is read one unit ahead, so its latency stays hidden.  n_chunks < 2^31 (checked on the host).
@@ -880,9 +857,9 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     int64_t t0 = 0;
     if (chunk < n_chunks32) {
         const unsigned row = chunk / cpr32;
-        t0 = (int64_t)(chunk - row * cpr32) * CHUNK;
+        t0 = (int64_t)(chunk - row * cpr32) * CSTEP;
         load_chunk_iq(pre, iq + row * S, t0, S, lane);
-        if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
+        if (lane < CSTEP && t0 + lane < LT) pre_tg = gsrc[row * LT + t0 + lane];
     }
     while (chunk < n_chunks32) {
 #ifdef ABL_TIMING
@@ -907,9 +884,9 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         pre_tg = make_float2(0.f, 0.f);
         if (chunk < n_chunks32) {
             const unsigned row = chunk / cpr32;
-            t0 = (int64_t)(chunk - row * cpr32) * CHUNK;
+            t0 = (int64_t)(chunk - row * cpr32) * CSTEP;
             load_chunk_iq(pre, iq + row * S, t0, S, lane);
-            if (t0 + lane < L) pre_tg = gsrc[row * L + t0 + lane];
+            if (lane < CSTEP && t0 + lane < LT) pre_tg = gsrc[row * LT + t0 + lane];
         }
         __builtin_amdgcn_wave_barrier();
         // (measured: starting FC1 of the second pair inside the output stage of the first, the one stretch
@@ -917,12 +894,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             // tiles beyond L inside a started pair run with zero upstream gradient: they add nothing
-            if (t0_cur + 32 * p >= L) break;
+            if (t0_cur + PSTEP * p >= LT) break;
 #ifdef ABL_TIMING
             tk = 0;
             PHASE();   // slot 0: everything outside the pair code (staging, prefetch, loop control)
 #endif
-            const int cA = 2 * p, cB = 2 * p + 1;
+            const int cA = 4 * PSTEP * p, cB = cA + 64;   // byte offsets of the two tiles in the series
             Tile A, B;
             Fc1Operand bA, bB;
             F1(bA, cA);
@@ -1075,11 +1052,15 @@ int gen_mfma_pa_forward(const GenProblem &p, const float *cre, const float *cim,
 }
 
 int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *target, float *slab, int *n_partials,
-                      hipStream_t st) {
+                      hipStream_t st, const GenPaChain *chain) {
     const float2 *iq = reinterpret_cast<const float2 *>(p.x);
-    const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
+    // chain: chunks of 56 PA outputs over rows of OL = L - 4; otherwise chunks of 64 generator outputs
+    const int64_t rowlen = chain ? p.L - (PA_M - 1) : p.L, cstep = chain ? PA_CHUNK : CHUNK;
+    const int64_t cpr = (rowlen + cstep - 1) / cstep, n_chunks = cpr * p.B;
     DPD_REQUIRE(n_chunks < ((int64_t)1 << 31) - 4096 && p.S < ((int64_t)1 << 31), DPD_ERR_SHAPE,
-                "gen_backward: %lld chunks of 64 samples exceed the 32-bit chunk counter", (long long)n_chunks);
+                "gen_backward: %lld chunks exceed the 32-bit chunk counter", (long long)n_chunks);
+    DPD_REQUIRE(!chain || (chain->M == PA_M && chain->K >= 1 && chain->K <= 4 && rowlen >= 1), DPD_ERR_INVALID_ARG,
+                "gen_backward: the fused chain is built for M = 5 taps and K <= 4 orders");
     const int gridn = mfma_grid(n_chunks, BWD_WAVES_PER_SIMD);
     *n_partials = gridn;
     // chunk counter: one word behind the largest slab this call can write (the workspace is far larger);
@@ -1088,20 +1069,19 @@ int gen_mfma_backward(const GenProblem &p, const float *grad_out, const float *t
     if (queue) DPD_HIP(hipMemsetAsync(queue, 0, sizeof(unsigned), st));
     const dim3 grid(gridn), block(WAVES * 64);
     const bool mse = grad_out == nullptr;
-    const float mse_scale = mse ? (float)(2.0 / (2.0 * (double)p.N)) : 0.f;
+    const double n_elem = 2.0 * (double)p.B * (double)rowlen;          // elements of the tensor the loss averages over
+    const float mse_scale = mse ? (float)(2.0 / n_elem) : 0.f;
     const float2 *go = reinterpret_cast<const float2 *>(grad_out), *tg = reinterpret_cast<const float2 *>(target);
-    static bool lds_allowed = !GEN_FC1_BF16;
-    if (!lds_allowed) {
-        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_bwd_mfma<true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
-        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_bwd_mfma<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
-        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_bwd_mfma<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
-        DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gen_bwd_mfma<false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)BWD_LDS_BYTES));
-        lds_allowed = true;
+    const PaBwdArgs pa = chain ? PaBwdArgs{chain->cre, chain->cim, chain->K, rowlen} : PaBwdArgs{nullptr, nullptr, 0, 0};
+#define GO(Q, M, P) hipLaunchKernelGGL((k_gen_bwd_mfma<Q, M, P>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
+                                       p.slope, p.absmax, go, tg, mse_scale, slab, queue, pa)
+    if (chain) {
+        if (p.qat) { if (mse) GO(true, true, true); else GO(true, false, true); }
+        else       { if (mse) GO(false, true, true); else GO(false, false, true); }
+    } else {
+        if (p.qat) { if (mse) GO(true, true, false); else GO(true, false, false); }
+        else       { if (mse) GO(false, true, false); else GO(false, false, false); }
     }
-#define GO(Q, M) hipLaunchKernelGGL((k_gen_bwd_mfma<Q, M>), grid, block, GEN_FC1_BF16 ? BWD_LDS_BYTES : 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
-                                    p.slope, p.absmax, go, tg, mse_scale, slab, queue)
-    if (p.qat) { if (mse) GO(true, true); else GO(true, false); }
-    else       { if (mse) GO(false, true); else GO(false, false); }
 #undef GO
     DPD_LAUNCH_CHECK();
     return DPD_OK;

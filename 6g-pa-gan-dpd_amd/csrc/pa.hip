@@ -92,7 +92,39 @@ __global__ __launch_bounds__(256) void k_pa_bwd(const float2 *__restrict__ x, in
     }
 }
 
+// gy = (y - t) * scale element by element, and one partial sum of (y - t)^2 per workgroup (fixed order inside)
+__global__ __launch_bounds__(256) void k_mse_grad(const float *__restrict__ y, const float *__restrict__ t, int64_t n,
+                                                  float scale, float *__restrict__ gy, double *__restrict__ part) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float d = y[i] - t[i];
+        gy[i] = d * scale;
+        acc += (double)d * (double)d;
+    }
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(64) void k_mse_final(const double *__restrict__ part, int n, double inv_n, float *__restrict__ loss) {
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) a += part[i];
+    a = wave_sum_d(a);
+    if (threadIdx.x == 0) loss[0] = (float)(a * inv_n);
+}
+
 }  // namespace
+
+// gy = d mean((y - t)^2) / d y over n elements and loss[0] = that mean; part: scratch of 1024 doubles
+int pa_launch_mse_grad(const float *y, const float *t, int64_t n, float *gy, double *part, float *loss, hipStream_t st) {
+    const int grid = grid_for(n, 256, 1024);
+    hipLaunchKernelGGL(k_mse_grad, dim3(grid), dim3(256), 0, st, y, t, n, (float)(2.0 / (double)n), gy, part);
+    DPD_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_mse_final, dim3(1), dim3(64), 0, st, part, grid, 1.0 / (double)n, loss);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
 
 static int pa_check(const float *x, int64_t B, int64_t S, const float *cre, const float *cim, int K, int M) {
     DPD_REQUIRE((x || B == 0) && cre && cim, DPD_ERR_INVALID_ARG, "pa: null pointer");

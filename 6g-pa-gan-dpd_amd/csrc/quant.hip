@@ -35,7 +35,97 @@ __global__ __launch_bounds__(256) void k_row_fq(const float *__restrict__ x, int
     }
 }
 
+struct QRange {
+    float scale, qmin, qmax;
+};
+DEV float fq_fixed(float v, QRange r) { return fminf(fmaxf(rintf(v * r.scale), r.qmin), r.qmax) / r.scale; }
+
+// out[n, o] = fq_a( sum_i fq_a(x[n, i]) * fq_w(w[o, i]) + bias[o] ).  Every product of two fp32 values is
+// exact in fp64 and the fp64 sum of `in` of them carries an error far below the output grid, so the result
+// is that of exact arithmetic (for the power-of-two scales of the Q8.8 / Q1.15 formats: of the integer
+// datapath) and does not depend on a summation order.  One lane per output; the row of x is re-read by the
+// lanes of a workgroup through the cache.
+__global__ __launch_bounds__(256) void k_qlinear_fwd(const float *__restrict__ x, const float *__restrict__ w,
+                                                     const float *__restrict__ bias, int64_t N, int in, int out_f,
+                                                     QRange ra, QRange rw, float *__restrict__ out) {
+    const int64_t total = N * out_f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t n = e / out_f;
+        const int o = (int)(e - n * out_f);
+        const float *xr = x + n * in, *wr = w + (int64_t)o * in;
+        double acc = 0.0;
+        for (int i = 0; i < in; ++i) acc += (double)fq_fixed(xr[i], ra) * (double)fq_fixed(wr[i], rw);
+        if (bias) acc += (double)bias[o];
+        const double q = fmin(fmax(rint(acc * (double)ra.scale), (double)ra.qmin), (double)ra.qmax);
+        out[e] = (float)q / ra.scale;
+    }
+}
+
+// Straight-through backward: gx = gy fq_w(W), gw = gy^T fq_a(x), gb = column sums of gy (fp32, fixed order).
+__global__ __launch_bounds__(256) void k_qlinear_gx(const float *__restrict__ gy, const float *__restrict__ w, int64_t N,
+                                                    int in, int out_f, QRange rw, float *__restrict__ gx) {
+    const int64_t total = N * in;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t n = e / in;
+        const int i = (int)(e - n * in);
+        float acc = 0.f;
+        for (int o = 0; o < out_f; ++o) acc = __builtin_fmaf(gy[n * out_f + o], fq_fixed(w[(int64_t)o * in + i], rw), acc);
+        gx[e] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void k_qlinear_gw(const float *__restrict__ gy, const float *__restrict__ x, int64_t N,
+                                                    int in, int out_f, QRange ra, float *__restrict__ gw,
+                                                    float *__restrict__ gb) {
+    const int total = out_f * (in + 1);          // column `in` of a row is the bias gradient
+    for (int e = blockIdx.x * 256 + threadIdx.x; e < total; e += gridDim.x * 256) {
+        const int o = e / (in + 1), i = e - o * (in + 1);
+        double acc = 0.0;
+        for (int64_t n = 0; n < N; ++n) acc += (double)gy[n * out_f + o] * (i < in ? (double)fq_fixed(x[n * in + i], ra) : 1.0);
+        if (i < in) gw[o * in + i] = (float)acc;
+        else if (gb) gb[o] = (float)acc;
+    }
+}
+
 }  // namespace
+
+static QRange qrange_of(float scale, int bits, int is_signed) {
+    return QRange{scale, is_signed ? -(float)(1 << (bits - 1)) : 0.f,
+                  is_signed ? (float)((1 << (bits - 1)) - 1) : (float)((1 << bits) - 1)};
+}
+
+extern "C" int dpd_quantized_linear(const float *x, const float *w, const float *bias, int64_t N, int in_features,
+                                    int out_features, float act_scale, int act_bits, int act_signed, float w_scale,
+                                    int w_bits, int w_signed, float *out, void *stream) {
+    DPD_REQUIRE(((x && out) || N == 0) && w && N >= 0 && in_features >= 1 && out_features >= 1, DPD_ERR_INVALID_ARG,
+                "quantized_linear: bad argument");
+    DPD_REQUIRE(act_bits >= 2 && act_bits <= 24 && w_bits >= 2 && w_bits <= 24, DPD_ERR_INVALID_ARG, "quantized_linear: bits not in 2..24");
+    if (N == 0) return DPD_OK;
+    hipLaunchKernelGGL(k_qlinear_fwd, dim3(grid_for(N * out_features, 256)), dim3(256), 0, as_stream(stream), x, w, bias, N,
+                       in_features, out_features, qrange_of(act_scale, act_bits, act_signed),
+                       qrange_of(w_scale, w_bits, w_signed), out);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+extern "C" int dpd_quantized_linear_backward(const float *x, const float *w, const float *gy, int64_t N, int in_features,
+                                             int out_features, float act_scale, int act_bits, int act_signed,
+                                             float w_scale, int w_bits, int w_signed, float *gx, float *gw, float *gb,
+                                             void *stream) {
+    DPD_REQUIRE(((x && gy) || N == 0) && w && N >= 0 && in_features >= 1 && out_features >= 1, DPD_ERR_INVALID_ARG,
+                "quantized_linear_backward: bad argument");
+    hipStream_t st = as_stream(stream);
+    if (gx && N > 0) {
+        hipLaunchKernelGGL(k_qlinear_gx, dim3(grid_for(N * in_features, 256)), dim3(256), 0, st, gy, w, N, in_features,
+                           out_features, qrange_of(w_scale, w_bits, w_signed), gx);
+        DPD_LAUNCH_CHECK();
+    }
+    if (gw) {
+        hipLaunchKernelGGL(k_qlinear_gw, dim3(grid_for((int64_t)out_features * (in_features + 1), 256)), dim3(256), 0, st, gy,
+                           x, N, in_features, out_features, qrange_of(act_scale, act_bits, act_signed), gw, gb);
+        DPD_LAUNCH_CHECK();
+    }
+    return DPD_OK;
+}
 
 extern "C" int dpd_quantize_fixed(const float *x, int64_t n, float scale, int bits, int is_signed, int dequant,
                                   float *out, void *stream) {

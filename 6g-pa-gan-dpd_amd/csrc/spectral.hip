@@ -89,6 +89,58 @@ __global__ __launch_bounds__(TPB) void k_spectral_stats(const float2 *__restrict
     }
 }
 
+// Row lengths that are not a power of two (the reference's torch.fft.fft takes any length, e.g. the 4,087
+// PA outputs of a 4,096-sample validation slice): the band powers from a direct DFT, O(L^2) per row, with
+// the L twiddles exp(-2 pi i r / L) tabulated in LDS and the phase index r = k n mod L advanced exactly in
+// integers.  One workgroup per row; a metrics path (forward only), not a training path.
+__global__ __launch_bounds__(TPB) void k_spectral_stats_dft(const float2 *__restrict__ pred,
+                                                            const float2 *__restrict__ target, int64_t L,
+                                                            const uint8_t *__restrict__ band, float *__restrict__ stats) {
+    extern __shared__ float2 lds2[];
+    float2 *tw = lds2;
+    __shared__ float red[4];
+    const int64_t b = blockIdx.x;
+    const float2 *p = pred + b * L;
+    const int n_len = (int)L;
+    for (int r = threadIdx.x; r < n_len; r += TPB) {
+        float sn, cs;
+        sincospif(2.0f * (float)r / (float)n_len, &sn, &cs);
+        tw[r] = make_float2(cs, -sn);
+    }
+    float s_abs = 0.f, s_err = 0.f, s_ref = 0.f;
+    for (int i = threadIdx.x; target && i < n_len; i += TPB) {
+        const float2 v = p[i], t = target[b * L + i];
+        const float dx = v.x - t.x, dy = v.y - t.y;
+        s_abs += fabsf(dx) + fabsf(dy);
+        s_err += dx * dx + dy * dy;
+        s_ref += t.x * t.x + t.y * t.y;
+    }
+    __syncthreads();
+    float pm = 0.f, pl = 0.f, pu = 0.f;
+    const float invL = 1.0f / (float)L;
+    for (int k = threadIdx.x; k < n_len; k += TPB) {
+        float xr = 0.f, xi = 0.f;
+        int r = 0;
+        for (int n = 0; n < n_len; ++n) {
+            const float2 v = p[n], w = tw[r];
+            xr += v.x * w.x - v.y * w.y;
+            xi += v.x * w.y + v.y * w.x;
+            r += k;
+            if (r >= n_len) r -= n_len;
+        }
+        const float pw = (xr * xr + xi * xi) * invL;
+        pm += band[k] ? pw : 0.f;
+        pl += band[L + k] ? pw : 0.f;
+        pu += band[2 * L + k] ? pw : 0.f;
+    }
+    float r0 = block_sum(s_abs, red), r1 = block_sum(s_err, red), r2 = block_sum(s_ref, red);
+    float r3 = block_sum(pm, red), r4 = block_sum(pl, red), r5 = block_sum(pu, red);
+    if (threadIdx.x == 0) {
+        float *o = stats + b * 8;
+        o[0] = r0; o[1] = r1; o[2] = r2; o[3] = r3; o[4] = r4; o[5] = r5; o[6] = 0.f; o[7] = 0.f;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void k_spectral_bwd(const float2 *__restrict__ pred,
                                                       const float2 *__restrict__ target, int64_t L, int log2n,
                                                       const uint8_t *__restrict__ band,
@@ -751,9 +803,16 @@ extern "C" int dpd_spectral_stats(const float *pred, const float *target, int64_
     DPD_REQUIRE(((pred && stats && (band || target)) || B <= 0), DPD_ERR_INVALID_ARG, "spectral_stats: null pointer");
     DPD_REQUIRE(L >= 1, DPD_ERR_INVALID_ARG, "spectral_stats: empty rows");
     int log2n = 0;
-    DPD_REQUIRE(!band || check_len(L, &log2n), DPD_ERR_INVALID_ARG,
-                "spectral_stats: row length %lld is not a power of two in 2..4096", (long long)L);
+    const bool pow2 = check_len(L, &log2n);
+    DPD_REQUIRE(!band || pow2 || (L >= 2 && L <= 8192), DPD_ERR_INVALID_ARG,
+                "spectral_stats: row length %lld is neither a power of two in 2..4096 nor within the direct-DFT limit of 8192", (long long)L);
     if (B <= 0) return DPD_OK;
+    if (band && !pow2) {
+        hipLaunchKernelGGL(k_spectral_stats_dft, dim3((unsigned)B), dim3(TPB), (size_t)L * sizeof(float2), as_stream(stream),
+                           reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), L, band, stats);
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
     if (band && L == 1024) {
         hipLaunchKernelGGL(w1024::k_stats, dim3(w1024::grid_for_rows(B)), dim3(w1024::ROWS_PER_BLOCK * 64), 0,
                            as_stream(stream), reinterpret_cast<const float2 *>(pred),

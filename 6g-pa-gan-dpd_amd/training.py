@@ -49,6 +49,13 @@ class Stage1Step:
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g.view_as(p)
 
+    def _core(self, iq, target, B, S, qat, st):
+        _, wsp, wsn = L.workspace(iq.device)
+        loss = self.grads[L.GEN_NPARAM:L.GEN_NPARAM + 1]
+        L.call("dpd_gen_mse_step", L.fptr(iq), B, S, L.fptr(target), L.fptr(self.wq), float(self.gen.leaky_slope), int(qat),
+               L.fptr(self.absmax), L.fptr(self.grads), L.fptr(loss), wsp, wsn, self.impl, st)
+        return loss
+
     def __call__(self, iq: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
         gen = self.gen
         self._bind_grads()
@@ -65,16 +72,33 @@ class Stage1Step:
                        L.fptr(self.absmax), L.fptr(self.scratch_out), self.impl, st)
                 if self.absmax_sync is not None:
                     self.absmax_sync(self.absmax[stage:stage + 1])
-        _, wsp, wsn = L.workspace(iq.device)
-        loss = self.grads[L.GEN_NPARAM:L.GEN_NPARAM + 1]
-        L.call("dpd_gen_mse_step", L.fptr(iq), B, S, L.fptr(target), L.fptr(self.wq), float(gen.leaky_slope), int(qat),
-               L.fptr(self.absmax), L.fptr(self.grads), L.fptr(loss), wsp, wsn, self.impl, st)
+        loss = self._core(iq, target, B, S, qat, st)
         if self.grad_sync is not None:
             self.grad_sync(self.grads)          # gradients and the loss in one buffer: one all-reduce
         if qat and gen.training:
             for i, name in enumerate(gen.ACT_QUANT + gen.WEIGHT_QUANT):
                 getattr(gen, name).observe(self.absmax[i])
         self.opt.step()
+        return loss
+
+
+class ChainStep(Stage1Step):
+    """Supervised step through the PA twin: loss = MSE(PA(G(iq)), target) with target [B, L-4, 2]; Adam update
+    of the generator.  Generator forward, output quantiser, PA twin, loss, PA adjoint and generator backward run
+    in one fused kernel (dpd_gen_pa_mse_step); the QAT abs-max passes precede it as in Stage1Step."""
+
+    def __init__(self, generator, pa, **kw):
+        super().__init__(generator, **kw)
+        vpa = getattr(pa, "pa_model", pa)
+        self.cre, self.cim = L.as_f32(vpa.coeffs_real), L.as_f32(vpa.coeffs_imag)
+
+    def _core(self, iq, target, B, S, qat, st):
+        K, M = self.cre.shape
+        _, wsp, wsn = L.workspace(iq.device, B * (S - 5))
+        loss = self.grads[L.GEN_NPARAM:L.GEN_NPARAM + 1]
+        L.call("dpd_gen_pa_mse_step", L.fptr(iq), B, S, L.fptr(target), L.fptr(self.wq), float(self.gen.leaky_slope),
+               int(qat), L.fptr(self.absmax), L.fptr(self.cre), L.fptr(self.cim), K, M, L.fptr(self.grads), L.fptr(loss),
+               wsp, wsn, st)
         return loss
 
 

@@ -7,7 +7,7 @@ csrc/quant.hip, integer inference in csrc/q88.hip."""
 import struct
 from dataclasses import dataclass
 from pathlib import Path
-from typing import Dict, Tuple, Union
+from typing import Dict, Optional, Tuple, Union
 
 import numpy as np
 import torch
@@ -90,6 +90,39 @@ def fake_quantize_grad(tensor: torch.Tensor, scale: float, bits: int, signed: bo
     return FakeQuantizeFunction.apply(tensor, scale, bits, signed)
 
 
+class _QuantizedLinearFn(torch.autograd.Function):
+    """fq_a(fq_a(x) fq_w(W)^T + b) in one kernel with an exactly formed sum; straight-through backward."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, cfg):
+        L.need_gpu(x, weight)
+        xc, wc = L.as_f32(x), L.as_f32(weight)
+        bc = L.as_f32(bias) if bias is not None else None
+        out_f, in_f = wc.shape
+        x2 = xc.reshape(-1, in_f)
+        out = torch.empty(x2.shape[0], out_f, dtype=torch.float32, device=xc.device)
+        ctx.q = (float(cfg.activation_scale), int(cfg.activation_bits), int(cfg.activation_signed),
+                 float(cfg.weight_scale), int(cfg.weight_bits), int(cfg.weight_signed))
+        L.call("dpd_quantized_linear", L.fptr(x2), L.fptr(wc), L.fptr(bc), x2.shape[0], in_f, out_f, *ctx.q, L.fptr(out),
+               L.stream())
+        ctx.save_for_backward(x2, wc)
+        ctx.has_bias = bias is not None
+        return out.reshape(*xc.shape[:-1], out_f)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x2, wc = ctx.saved_tensors
+        out_f, in_f = wc.shape
+        g2 = L.as_f32(gy).reshape(-1, out_f)
+        need_x, need_w, need_b = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.has_bias and ctx.needs_input_grad[2]
+        gx = torch.empty_like(x2) if need_x else None
+        gw = torch.empty_like(wc) if (need_w or need_b) else None
+        gb = torch.empty(out_f, dtype=torch.float32, device=wc.device) if need_b else None
+        L.call("dpd_quantized_linear_backward", L.fptr(x2), L.fptr(wc), L.fptr(g2), x2.shape[0], in_f, out_f, *ctx.q,
+               L.fptr(gx), L.fptr(gw), L.fptr(gb), L.stream())
+        return (gx.reshape(*gy.shape[:-1], in_f) if need_x else None), (gw if need_w else None), gb, None
+
+
 class QuantizedLinear(nn.Module):
     """fq(x, 2^8) @ fq(W, 2^15)^T + bias, then fq(., 2^8): the fixed-scale datapath statement."""
 
@@ -103,11 +136,7 @@ class QuantizedLinear(nn.Module):
             self.register_parameter("bias", None)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        c = self.config
-        x_q = fake_quantize_grad(x, c.activation_scale, c.activation_bits, c.activation_signed)
-        w_q = fake_quantize_grad(self.weight, c.weight_scale, c.weight_bits, c.weight_signed)
-        out = torch.nn.functional.linear(x_q, w_q, self.bias)
-        return fake_quantize_grad(out, c.activation_scale, c.activation_bits, c.activation_signed)
+        return _QuantizedLinearFn.apply(x, self.weight, self.bias, self.config)
 
     def get_quantized_weights(self) -> Dict[str, torch.Tensor]:
         c = self.config
@@ -192,7 +221,9 @@ class Q88Inference:
         safe = L.lib().dpd_q88_int32_safe(*(L.c_p(t.data_ptr()) for t in host))
         self.acc64 = bool(force_acc64 or not safe)
 
-    def __call__(self, iq: torch.Tensor) -> torch.Tensor:
+    def __call__(self, iq: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """`out` (optional, int16 [B, S-5, 2], contiguous) receives the result in place of a new tensor: a
+        streaming caller writes chunk after chunk into one resident buffer without a copy."""
         L.need_gpu(iq)
         if iq.dtype != torch.int16:
             raise RuntimeError("Q88Inference expects int16 Q1.15 IQ")
@@ -200,7 +231,10 @@ class Q88Inference:
         B, S = x.shape[0], x.shape[1]
         if S <= 5:
             raise ValueError(f"Sequence length {S} must be > memory depth 5")
-        out = torch.empty(B, S - 5, 2, dtype=torch.int16, device=x.device)
+        if out is None:
+            out = torch.empty(B, S - 5, 2, dtype=torch.int16, device=x.device)
+        elif tuple(out.shape) != (B, S - 5, 2) or out.dtype != torch.int16 or not out.is_contiguous():
+            raise RuntimeError(f"out must be a contiguous int16 tensor of shape {(B, S - 5, 2)}")
         i16 = torch.int16
         L.call("dpd_q88_infer", L.fptr(x, i16), B, S, *(L.fptr(self.w[k], i16) for k in ("w1", "b1", "w2", "b2", "w3", "b3")),
                L.fptr(self.w["lut"], i16), int(self.acc64), L.fptr(out, i16), L.stream())

@@ -43,8 +43,13 @@ class _RowStatsFn(torch.autograd.Function):
         t = L.as_f32(target) if target is not None else None
         B, n = p.shape[0], p.shape[1]
         stats = torch.zeros(B, 8, dtype=torch.float32, device=p.device)
-        if band is not None and (n & (n - 1) or n < 2 or n > 4096):
-            raise NotImplementedError(f"ACPR on the HIP path needs a power-of-two row length in 2..4096, got {n}")
+        pow2 = not (n & (n - 1) or n < 2 or n > 4096)
+        if band is not None and not pow2:
+            # other lengths: direct DFT, forward only (metrics on rows such as the 4,087 PA outputs of a 4,096-sample slice)
+            if n < 2 or n > 8192:
+                raise NotImplementedError(f"ACPR on the HIP path needs a row length of a power of two in 2..4096 or any length up to 8192, got {n}")
+            if pred.requires_grad:
+                raise NotImplementedError(f"ACPR gradients on the HIP path need a power-of-two row length in 2..4096, got {n}")
         L.call("dpd_spectral_stats", L.fptr(p), L.fptr(t), B, n, L.fptr(band, torch.uint8), L.fptr(stats), L.stream())
         ctx.save_for_backward(p, t if t is not None else p.new_empty(0), band if band is not None else p.new_empty(0))
         ctx.flags = (t is not None, band is not None)

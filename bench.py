@@ -1,67 +1,104 @@
 #!/usr/bin/env python3
 """Throughput of the batched DPD hot path on MI355X, in IQ samples/s.
 
-  python bench.py --gpus N --steps K --warmup W [--workload stage1|stage1_qat|stage2|q88|gen_pa|spectral] [--extras]
+  python bench.py --gpus N --steps K --warmup W
+        [--workload stage2|stage1|stage1_qat|q88|q88_stream|gen_pa|gen_pa_train|spectral]
+        [--no-extras] [--no-cpu-baseline] [--global-samples G [--global-batch Bg]]
 
 A step is one pass of the workload over one batch of synthetic OFDM-like IQ rows that is already
-resident in HBM (per GPU: 16384 rows of 1029 samples -> 2^24 generator outputs).  With N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank holds its own 2^24 samples (weak
-scaling), rows are never exchanged, and the flat gradient buffers are all-reduced over RCCL once
-per backward.  Rank 0 prints one JSON line.
+resident in HBM (per GPU: 16384 rows of 1029 samples -> 2^24 generator outputs).
 
-Headline workload (`stage1`): the Stage-1 supervised MSE training step of the reference's two-stage
-schedule (generator forward + MSE + backward fused in one kernel, then Adam).  `--extras` adds short
-measurements of the other workloads under "extra" in the same JSON line.
+Headline workload (`stage2`, BASELINE.json configs[2]): one CWGAN-GP training step -- 5 critic updates
+(Wasserstein terms + gradient penalty with its double backward) and one generator update (adversarial +
+L1 + SpectralLoss with the row FFT), QAT generator, Adam.  The other workloads (Stage-1 step with and
+without QAT, Q8.8 integer inference, the generator -> PA chain forward and with its fused backward,
+SpectralLoss) are timed briefly in the same run and reported under "extra", each with the roofline
+of its dominant kernel (timed with HIP events on the launch stream) and a CPU baseline.
+
+N > 1: one rank per GPU.  Launched by torch.distributed.run the ranks are already there; called as
+plain `python bench.py --gpus N` this process starts them (before it touches a GPU) and passes the
+ranks' JSON line through.  Weak scaling by default (every rank holds its own 2^24 samples, rows are
+never exchanged, flat gradient buffers and QAT scales are all-reduced over RCCL).
+`--global-samples G` switches to a fixed global problem (BASELINE.json configs[3]: G = 2^28): G samples
+are split over the ranks and one step is G / Bg optimiser steps on global batches of Bg samples
+(default 2^24), each with its gradient all-reduce; "scaling" is then "strong".
+Rank 0 prints one JSON line.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import torch  # noqa: E402
-
-FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 vector == fp32 MFMA dense peak
+FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 vector == fp32 MFMA dense peak (256 CU x 4 SIMD x 64 flop/cycle x 2.4 GHz)
 HBM_PEAK_GBS = 8000.0
+CLOCK_HZ = 2.4e9
+N_SIMD = 1024
 GEN_FWD_MAC, GEN_BWD_MAC = 1504, 2048           # per sample: 30x32 + 32x16 + 16x2 ; backward without input gradient
 CRITIC_FWD_MAC, CRITIC_BWD_MAC, CRITIC_DX_MAC = 2832, 5408, 2704
+PA_FLOP = 200                                   # memory polynomial, 4 orders x 5 taps (complex Horner form)
+PA_BWD_FLOP = 400
+# MFMA instructions the critic's fused mean-score pass (forward + backward) issues per tile of 16 samples, with
+# their issue cycles per SIMD (counted in the kernel's assembly): the fp32 products run on
+# v_mfma_f32_16x16x4_f32 (32 cycles) and v_mfma_f32_4x4x1_16b_f32 (8), the hidden-layer products as three-way-split
+# bf16 operands on v_mfma_f32_16x16x32_bf16 (16) and v_mfma_f32_16x16x16_bf16 (8)
+CRITIC_BWD_MFMA_CYCLES = 44 * 32 + 16 * 8 + 54 * 16 + 12 * 8
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="stage1",
-                    choices=["stage1", "stage1_qat", "stage2", "q88", "q88_stream", "gen_pa", "spectral"])
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="stage2",
+                    choices=["stage2", "stage1", "stage1_qat", "q88", "q88_stream", "gen_pa", "gen_pa_train", "spectral"])
     ap.add_argument("--stream-chunks", type=int, default=32, help="q88_stream: chunks of --rows rows per step (32 x 2^24 = 2^29 samples)")
     ap.add_argument("--rows", type=int, default=16384)
     ap.add_argument("--seq", type=int, default=1029)
-    ap.add_argument("--extras", action="store_true", help="also time the other workloads briefly")
+    ap.add_argument("--global-samples", type=int, default=0, help="fixed global problem size in samples (strong scaling), e.g. 268435456")
+    ap.add_argument("--global-batch", type=int, default=1 << 24, help="with --global-samples: samples per optimiser step over all ranks")
+    ap.add_argument("--extras", action="store_true", help="(default now; kept for older command lines)")
+    ap.add_argument("--no-extras", action="store_true", help="only the headline workload")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a child job.  Runs
+    before anything in this process touches a GPU; the child's exit code is this process's exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 class Ctx:
     def __init__(self, args):
+        import torch
         import torch.distributed as dist
-        self.dist = dist
+        self.torch, self.dist = torch, dist
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         # DPD_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- exercises the N > 1 code
         # path on a one-GPU box (numbers from such a run mean nothing)
-        rehearsal = os.environ.get("DPD_BENCH_REHEARSAL") == "1"
-        if rehearsal:
+        self.rehearsal = os.environ.get("DPD_BENCH_REHEARSAL") == "1"
+        if self.rehearsal:
             self.local = 0
         torch.cuda.set_device(self.local)
         self.dev = torch.device("cuda", self.local)
         if self.world > 1:
-            if rehearsal:
+            if self.rehearsal:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=self.dev)
@@ -69,15 +106,26 @@ class Ctx:
         from dpd_amd.data import ofdm_rows
         from dpd_amd.parallel import DataParallel
         self.dp = DataParallel()
-        self.rows, self.seq = args.rows, args.seq
-        self.iq = ofdm_rows(args.rows, args.seq, seed=1234 + self.rank, device=self.dev)
-        self.target = self.iq[:, 5:, :].contiguous()
-        self.n_local = args.rows * (args.seq - 5)
+        self.seq = args.seq
+        L = args.seq - 5
+        self.micro = 1
+        if args.global_samples:
+            per_step = args.global_batch // self.world            # samples per rank and optimiser step
+            self.rows = max(per_step // L, 1)
+            self.micro = max(args.global_samples // max(args.global_batch, 1), 1)
+            self.strong = True
+        else:
+            self.rows, self.strong = args.rows, False
+        self.n_local = self.rows * L * self.micro               # samples this rank processes per bench step
+        # micro-batches are distinct row sets, all resident in HBM before the timed region
+        self.iqs = [ofdm_rows(self.rows, args.seq, seed=1234 + self.rank + 1000 * m, device=self.dev) for m in range(self.micro)]
+        self.targets = [iq[:, 5:, :].contiguous() for iq in self.iqs]
+        self.iq, self.target = self.iqs[0], self.targets[0]
 
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
-        torch.cuda.synchronize()
+        self.torch.cuda.synchronize()
 
     def timed(self, fn, steps, warmup):
         """W untimed + K timed steps between barrier+synchronize; max over ranks; seconds."""
@@ -90,23 +138,27 @@ class Ctx:
         self.barrier()
         dt = time.perf_counter() - t0
         if self.world > 1:
-            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            t = self.torch.tensor([dt], device=self.dev, dtype=self.torch.float64)
+            if self.rehearsal:
+                t = t.cpu()
             self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-            dt = t.item()
+            dt = float(t.item())
         return dt
 
 
 class KernelTimer:
-    """HIP events (torch.cuda.Event on the launch stream == torch's current stream, which is the stream
-    handed to the C ABI) around every call of one C-ABI entry point during the timed region."""
+    """HIP events (torch.cuda.Event on the launch stream: torch's current stream is the stream handed to
+    the C ABI) around every call of one C-ABI entry point during the timed region; `when` (optional)
+    selects the calls by their arguments."""
 
-    def __init__(self, name):
+    def __init__(self, name, when=None):
+        import torch
         from dpd_amd import _lib
-        self.lib, self.name, self.events, self.on = _lib, name, [], False
+        self.torch, self.lib, self.name, self.events, self.on, self.when = torch, _lib, name, [], False, when
         self.orig = _lib.call
 
         def call(n, *a):
-            if n != self.name or not self.on:
+            if n != self.name or not self.on or (self.when is not None and not self.when(a)):
                 return self.orig(n, *a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -119,31 +171,40 @@ class KernelTimer:
         self.lib.call = self.orig
 
     def avg_seconds(self):
+        self.torch.cuda.synchronize()
         ms = [a.elapsed_time(b) for a, b in self.events]
         return sum(ms) / max(len(ms), 1) * 1e-3
+
+
+def pmc_bytes(key):
+    """HBM bytes per launch of a kernel from the rocprofv3 counter passes recorded under profiles/
+    (TCC_EA read and write requests converted to bytes as the microarchitecture guide prescribes).  The counters cannot
+    be read from inside this process; the figures apply to the default shape only."""
+    for name in ("r2_pmc.json", "r1_stage1_pmc.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if key in d:
+                return int(d[key]["hbm_bytes"])
+            if key == "k_gen_bwd_mfma<false,true>" and "per_launch" in d:
+                return int(d["per_launch"]["hbm_bytes"])
+        except (OSError, KeyError, ValueError, TypeError):
+            continue
+    return None
+
+
+def default_shape(ctx):
+    return (ctx.rows, ctx.seq, ctx.micro) == (16384, 1029, 1)
 
 
 # ------------------------------------------------------------------------------------------ workloads
 def make_generator(ctx, qat):
     from dpd_amd.models import TDNNGeneratorQAT
-    torch.manual_seed(0)
+    ctx.torch.manual_seed(0)
     gen = TDNNGeneratorQAT().to(ctx.dev)
     gen.qat_enabled = qat
     return gen.train()
-
-
-def pmc_traffic(ctx, qat):
-    """HBM bytes per launch of the fused Stage-1 kernel from the rocprofv3 counter passes recorded under
-    profiles/ (FETCH_SIZE doubled, the gfx950 correction, + WRITE_SIZE).  The counters cannot be read
-    from inside this process; the figure applies to the default shape only, otherwise null."""
-    path = os.path.join(ROOT, "profiles", "r1_stage1_pmc.json")
-    if qat or (ctx.rows, ctx.seq) != (16384, 1029) or not os.path.exists(path):
-        return None
-    try:
-        with open(path) as f:
-            return int(json.load(f)["per_launch"]["hbm_bytes"])
-    except (OSError, KeyError, ValueError):
-        return None
 
 
 def run_stage1(ctx, args, qat, steps, warmup):
@@ -151,18 +212,28 @@ def run_stage1(ctx, args, qat, steps, warmup):
     gen = make_generator(ctx, qat)
     dp = ctx.dp
     step = Stage1Step(gen, grad_sync=dp.mean_ if dp.enabled else None, absmax_sync=dp.max_ if dp.enabled else None)
+
+    def fn():
+        for iq, tg in zip(ctx.iqs, ctx.targets):
+            step(iq, tg)
     kt = KernelTimer("dpd_gen_mse_step")
     for _ in range(warmup):
-        step(ctx.iq, ctx.target)
+        fn()
     kt.on = True
-    dt = ctx.timed(lambda: step(ctx.iq, ctx.target), steps, 0)
+    dt = ctx.timed(fn, steps, 0)
     kt.close()
     k = kt.avg_seconds()
-    flop = 2.0 * (GEN_FWD_MAC + GEN_BWD_MAC) * ctx.n_local
+    n = ctx.rows * (ctx.seq - 5)
+    flop = 2.0 * (GEN_FWD_MAC + GEN_BWD_MAC) * n
     roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma: tap assembly + forward + MSE + backward, fp32 MFMA (+ slab reduce)",
             "achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS, "traffic": pmc_traffic(ctx, qat),
+            "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS,
+            "traffic": pmc_bytes("k_gen_bwd_mfma<%s,true>" % ("true" if qat else "false")) if default_shape(ctx) else None,
             "flop_per_sample": 2 * (GEN_FWD_MAC + GEN_BWD_MAC), "kernel_ms": k * 1e3}
+    if qat:
+        # the four abs-max passes recompute the forward up to the layer whose scale they produce: work that the
+        # roofline does not credit.  Executed MACs per sample: pass 1 960, pass 2 1472, pass 3 1504, then the fused step
+        roof["note"] = "whole step also runs 4 abs-max passes (3,936 MAC/sample of recomputation, not credited)"
     loss = float(step.grads[1554].item())
     return dt, roof, {"loss": loss}
 
@@ -170,64 +241,90 @@ def run_stage1(ctx, args, qat, steps, warmup):
 def run_stage2(ctx, args, steps, warmup):
     from dpd_amd.models import Discriminator
     from dpd_amd.training import Stage2Step
+    torch = ctx.torch
     gen = make_generator(ctx, True)
     torch.manual_seed(1)
     disc = Discriminator().to(ctx.dev).train()
-    cond = ctx.target
     step = Stage2Step(gen, disc, dp=ctx.dp)
     info = {}
 
     def fn():
-        info.update(step(ctx.iq, ctx.target, cond))
-    dt = ctx.timed(fn, steps, warmup)
-    # algorithmic work of one step (n_critic = 5): per critic update one generator forward, two critic
-    # forward+backward passes (real, fake) and the gradient penalty (forward, input gradient, double
-    # backward); per generator update forward, critic forward + input gradient, generator backward
-    mac = 5 * (GEN_FWD_MAC + 2 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC) + (CRITIC_FWD_MAC + CRITIC_DX_MAC + CRITIC_BWD_MAC)) \
-        + (GEN_FWD_MAC + CRITIC_FWD_MAC + CRITIC_DX_MAC + GEN_BWD_MAC)
-    flop = 2.0 * mac * ctx.n_local
-    t = dt / steps
-    # the critic's hidden-layer products run on the bf16 matrix cores (three-way split operands, fp32
-    # accuracy): "achieved" is in fp32-equivalent flops and "frac" compares it with the fp32 peak
-    roof = {"bound": "mfma", "kernel": "whole step (critic kernels dominate; fp32-equivalent flops, part on bf16 matrix cores)",
-            "achieved": flop / t / 1e12,
-            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / t / 1e12 / FP32_PEAK_TFLOPS, "traffic": None,
-            "flop_per_sample": 2 * mac}
-    return dt, roof, {"g_total": float(info["g_total"].item())}
-
-
-def run_q88(ctx, args, steps, warmup):
-    from dpd_amd.utils import Q88Inference, export_q88_weights
-    gen = make_generator(ctx, True)
-    eng = Q88Inference(export_q88_weights(gen))
-    iq16 = (ctx.iq * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
-    out = [None]
-
-    def fn():
-        out[0] = eng(iq16)
-    kt = KernelTimer("dpd_q88_infer")
+        for iq, tg in zip(ctx.iqs, ctx.targets):
+            info.update(step(iq, tg, tg))
+    # dominant kernel: the critic's fused mean-score pass (forward + backward with weight gradients), launched
+    # twice per critic update (real, fake): dpd_critic_backward calls that ask for grads and not for gx
+    kt = KernelTimer("dpd_critic_backward", when=lambda a: a[7].value is not None and a[8].value is None)
     for _ in range(warmup):
         fn()
     kt.on = True
     dt = ctx.timed(fn, steps, 0)
     kt.close()
     k = kt.avg_seconds()
-    mac = GEN_FWD_MAC * ctx.n_local
+    n = ctx.rows * (ctx.seq - 5)
+    # algorithmic work of one step as executed (n_critic = 5): ONE generator forward serves the step; per critic
+    # update two critic forward+backward passes (real, fake) and the gradient penalty (forward, input gradient,
+    # double backward); for the generator update critic forward + input gradient and the generator backward
+    mac = GEN_FWD_MAC + 5 * (2 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC) + (CRITIC_FWD_MAC + CRITIC_DX_MAC + CRITIC_BWD_MAC)) \
+        + (CRITIC_FWD_MAC + CRITIC_DX_MAC + GEN_BWD_MAC)
+    t = dt / steps / ctx.micro
+    kflop = 2.0 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC) * n
+    tiles_per_simd = n / 16.0 / N_SIMD
+    issue_s = tiles_per_simd * CRITIC_BWD_MFMA_CYCLES / CLOCK_HZ
+    roof = {"bound": "mfma",
+            "kernel": "k_critic_bwd_mfma<true,false>: critic forward + backward with weight gradients in one pass "
+                      "(10 of the step's launches); fp32 MFMA for FC1 and the outer products, hidden-layer products as "
+                      "3-way-split bf16 operands on the bf16 MFMA (fp32 accuracy)",
+            # mixed-precision roofline: the time the kernel's MFMAs need at their peak issue rates (fp32 157.3 TFLOP/s,
+            # bf16 2.5 PFLOP/s dense) over the measured time, i.e. the MFMA issue-time fraction
+            "achieved": issue_s / k * FP32_PEAK_TFLOPS, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": issue_s / k,
+            "frac_definition": "MFMA issue time at peak rates / measured kernel time",
+            "mfma_issue_ms": issue_s * 1e3, "kernel_ms": k * 1e3,
+            "fp32_equivalent_tflops": kflop / k / 1e12, "flop_per_sample": 2 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC),
+            "traffic": pmc_bytes("k_critic_bwd_mfma<true,false>") if default_shape(ctx) else None,
+            "step_fp32_equivalent_tflops": 2.0 * mac * n / t / 1e12, "step_flop_per_sample": 2 * mac}
+    return dt, roof, {"g_total": float(info["g_total"].item())}
+
+
+def q88_engine(ctx):
+    from dpd_amd.utils import Q88Inference, export_q88_weights
+    gen = make_generator(ctx, True)
+    return Q88Inference(export_q88_weights(gen))
+
+
+def q88_roof(ctx, k, eng):
+    n = ctx.rows * (ctx.seq - 5)
+    mac = GEN_FWD_MAC * n
     # v_dot2c_i32_i16 issues at 16 lanes per SIMD-cycle (half the fp32 FMA rate; scratch/ubench/dot2_rate.hip
     # measures 36.4 T lane-instructions/s): 256 CU x 4 SIMD x 16 lanes x 2 MAC x 2.4 GHz = 78.6 TMAC/s
-    roof = {"bound": "valu-int", "kernel": "k_q88 (v_dot2c_i32_i16)", "achieved": mac / k / 1e12, "peak": 78.6,
-            "unit": "TMAC/s", "frac": mac / k / 1e12 / 78.6, "traffic": None, "hbm_gbs": 8.0 * ctx.n_local / k / 1e9,
-            "acc64": eng.acc64, "kernel_ms": k * 1e3}
-    return dt, roof, {"checksum": int(out[0].to(torch.int64).sum().item())}
+    return {"bound": "valu-int", "kernel": "k_q88 (v_dot2c_i32_i16)", "achieved": mac / k / 1e12, "peak": 78.6,
+            "unit": "TMAC/s", "frac": mac / k / 1e12 / 78.6, "traffic": pmc_bytes("k_q88") if default_shape(ctx) else None,
+            "hbm_gbs": 8.0 * n / k / 1e9, "acc64": eng.acc64, "kernel_ms": k * 1e3}
+
+
+def run_q88(ctx, args, steps, warmup):
+    torch = ctx.torch
+    eng = q88_engine(ctx)
+    iq16 = [(iq * 32768.0).round().clamp(-32768, 32767).to(torch.int16) for iq in ctx.iqs]
+    out = [None]
+
+    def fn():
+        for x in iq16:
+            out[0] = eng(x)
+    kt = KernelTimer("dpd_q88_infer")
+    for _ in range(warmup):
+        fn()
+    kt.on = True
+    dt = ctx.timed(fn, steps, 0)
+    kt.close()
+    return dt, q88_roof(ctx, kt.avg_seconds(), eng), {"checksum": int(out[0].to(torch.int64).sum().item())}
 
 
 def run_q88_stream(ctx, args, steps, warmup):
     """Q8.8 inference over a long int16 stream held in HBM, processed in chunks of `--rows` rows
     (2^24 outputs each at the default shape); `--stream-chunks` chunks per step.  The whole output of
     the first timed step is checksummed against a second, separate pass (bitwise reproducibility)."""
-    from dpd_amd.utils import Q88Inference, export_q88_weights
-    gen = make_generator(ctx, True)
-    eng = Q88Inference(export_q88_weights(gen))
+    torch = ctx.torch
+    eng = q88_engine(ctx)
     nchunk = args.stream_chunks
     g = torch.Generator(device=ctx.dev).manual_seed(4321 + ctx.rank)
     base = (ctx.iq * 32768.0).round().clamp(-32768, 32767).to(torch.int16)
@@ -237,7 +334,7 @@ def run_q88_stream(ctx, args, steps, warmup):
 
     def fn():
         for c in range(nchunk):
-            outs[c] = eng(stream[c])
+            eng(stream[c], out=outs[c])
 
     def checksum():
         v = outs.view(torch.int32).to(torch.int64)
@@ -251,120 +348,321 @@ def run_q88_stream(ctx, args, steps, warmup):
     kt.on = True
     dt = ctx.timed(fn, steps, 0)
     kt.close()
-    k = kt.avg_seconds()
     again = checksum()
-    mac = GEN_FWD_MAC * ctx.n_local
-    roof = {"bound": "valu-int", "kernel": "k_q88 (v_dot2c_i32_i16), per chunk", "achieved": mac / k / 1e12, "peak": 78.6,
-            "unit": "TMAC/s", "frac": mac / k / 1e12 / 78.6, "traffic": None, "hbm_gbs": 8.0 * ctx.n_local / k / 1e9,
-            "acc64": eng.acc64, "kernel_ms": k * 1e3}
-    return dt / nchunk, roof, {"stream_samples_per_gpu": ctx.n_local * nchunk, "checksum": again,
-                               "reproducible": bool(first == again) if warmup > 0 else None}
+    ctx.n_local = ctx.rows * (ctx.seq - 5) * nchunk
+    return dt, q88_roof(ctx, kt.avg_seconds(), eng), {"stream_samples_per_gpu": ctx.n_local, "checksum": again,
+                                                      "reproducible": bool(first == again) if warmup > 0 else None}
 
 
-def run_gen_pa(ctx, args, steps, warmup):
+def run_gen_pa(ctx, args, steps, warmup, qat=True):
     from dpd_amd.models import PADigitalTwin, dpd_pa_chain
-    gen = make_generator(ctx, True).eval()
+    gen = make_generator(ctx, qat).eval()
     pa = PADigitalTwin().to(ctx.dev)
     y = [None]
 
     def fn():
-        y[0] = dpd_pa_chain(gen, pa, ctx.iq, return_dpd=False)[1]
-    dt = ctx.timed(fn, steps, warmup)
-    flop = 2.0 * (GEN_FWD_MAC + 100) * ctx.n_local
-    t = dt / steps
-    roof = {"bound": "mfma", "kernel": "QAT generator: 4 abs-max passes, then output quantiser + PA twin in one kernel", "achieved": flop / t / 1e12,
-            "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / t / 1e12 / FP32_PEAK_TFLOPS, "traffic": None}
+        for iq in ctx.iqs:
+            y[0] = dpd_pa_chain(gen, pa, iq, return_dpd=False)[1]
+    # float generator: the whole chain is one kernel.  QAT: the dominant kernel is the last abs-max pass, a full
+    # generator forward that also writes the (unquantised) output; quantiser + PA follow in a streaming kernel
+    if qat:
+        kt = KernelTimer("dpd_gen_absmax_pass", when=lambda a: a[0] == 3)
+    else:
+        kt = KernelTimer("dpd_gen_pa_forward")
+    for _ in range(warmup):
+        fn()
+    kt.on = True
+    dt = ctx.timed(fn, steps, 0)
+    kt.close()
+    k = kt.avg_seconds()
+    n = ctx.rows * (ctx.seq - 5)
+    kflop = (2.0 * GEN_FWD_MAC + (0 if qat else PA_FLOP)) * n
+    flop = (2.0 * GEN_FWD_MAC + PA_FLOP) * n
+    t = dt / steps / ctx.micro
+    kname = ("k_gen_fwd_mfma<true,3,false>: tap assembly + QAT generator forward to the unquantised output (4th abs-max pass)" if qat else
+             "k_gen_fwd_mfma<false,4,true>: tap assembly + generator + PA twin in one kernel")
+    roof = {"bound": "mfma", "kernel": kname,
+            "achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kflop / k / 1e12 / FP32_PEAK_TFLOPS,
+            "traffic": pmc_bytes("k_gen_fwd_mfma<true,3,false>" if qat else "k_gen_fwd_mfma<false,4,true>") if default_shape(ctx) else None,
+            "flop_per_sample": 2 * GEN_FWD_MAC + (0 if qat else PA_FLOP), "kernel_ms": k * 1e3,
+            "chain_frac": flop / t / 1e12 / FP32_PEAK_TFLOPS}
+    if qat:
+        roof["note"] = ("chain_frac credits 3,208 flop/sample over the whole chain; the abs-max passes recompute 3,936 MAC/sample "
+                        "that are not credited, so its ceiling is 3,208 / (3,208 + 7,872) = 0.29 of peak")
     return dt, roof, {"y_rms": float(y[0].pow(2).mean().sqrt().item())}
+
+
+def run_gen_pa_train(ctx, args, steps, warmup):
+    """Generator -> PA twin with the fused backward: loss = MSE(PA(G(iq)), target), gradients of the generator."""
+    from dpd_amd.models import PADigitalTwin
+    from dpd_amd.training import ChainStep
+    gen = make_generator(ctx, True)
+    pa = PADigitalTwin().to(ctx.dev)
+    dp = ctx.dp
+    step = ChainStep(gen, pa, grad_sync=dp.mean_ if dp.enabled else None, absmax_sync=dp.max_ if dp.enabled else None)
+    tgs = [tg[:, 4:, :].contiguous() * 31.0 for tg in ctx.targets]
+
+    def fn():
+        for iq, tg in zip(ctx.iqs, tgs):
+            step(iq, tg)
+    kt = KernelTimer("dpd_gen_pa_mse_step")
+    for _ in range(warmup):
+        fn()
+    kt.on = True
+    dt = ctx.timed(fn, steps, 0)
+    kt.close()
+    k = kt.avg_seconds()
+    n = ctx.rows * (ctx.seq - 5)
+    flop = (2.0 * (GEN_FWD_MAC + GEN_BWD_MAC) + PA_FLOP + PA_BWD_FLOP) * n
+    roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma<QAT,PA>: tap assembly + generator + quantiser + PA twin + MSE + PA adjoint + generator backward",
+            "achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS,
+            "traffic": pmc_bytes("k_gen_bwd_mfma<true,pa>") if default_shape(ctx) else None,
+            "flop_per_sample": 2 * (GEN_FWD_MAC + GEN_BWD_MAC) + PA_FLOP + PA_BWD_FLOP, "kernel_ms": k * 1e3}
+    return dt, roof, {"loss": float(step.grads[1554].item())}
 
 
 def run_spectral(ctx, args, steps, warmup):
     from dpd_amd.utils import SpectralLoss
     sl = SpectralLoss()
-    pred = (ctx.target * 0.9).requires_grad_(True)
+    preds = [(tg * 0.9).requires_grad_(True) for tg in ctx.targets]
     val = [None]
 
     def fn():
-        pred.grad = None
-        val[0] = sl(pred, ctx.target)
-        val[0].backward()
-    dt = ctx.timed(fn, steps, warmup)
-    t = dt / steps
-    gbs = 40.0 * ctx.n_local / t / 1e9      # fwd: pred + target read (16 B); bwd: both again + dpred write (24 B)
-    roof = {"bound": "hbm", "kernel": "k_spectral_stats + k_spectral_bwd (row FFT in LDS)", "achieved": gbs,
-            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None}
+        for pred, tg in zip(preds, ctx.targets):
+            pred.grad = None
+            val[0] = sl(pred, tg)
+            val[0].backward()
+    ks, kb = KernelTimer("dpd_spectral_stats"), KernelTimer("dpd_spectral_backward")
+    for _ in range(warmup):
+        fn()
+    ks.on = kb.on = True
+    dt = ctx.timed(fn, steps, 0)
+    kb.close()
+    ks.close()
+    n = ctx.rows * (ctx.seq - 5)
+    t = dt / steps / ctx.micro
+    tk = ks.avg_seconds() + kb.avg_seconds()
+    gbs = 40.0 * n / tk / 1e9      # fwd: pred + target read (16 B); bwd: both again + dpred write (24 B)
+    roof = {"bound": "hbm", "kernel": "k_stats + k_bwd (row FFT in registers / LDS), the two streaming kernels", "achieved": gbs,
+            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": pmc_bytes("spectral") if default_shape(ctx) else None,
+            "bytes_per_sample": 40, "kernel_ms": tk * 1e3, "whole_loss_frac": 40.0 * n / t / 1e9 / HBM_PEAK_GBS}
     return dt, roof, {"loss": float(val[0].item())}
 
 
-def cpu_baseline_stage1(qat: bool, seq: int):
-    """The CPU oracle (vectorised torch fp32, all host threads given to the job) on a bounded sample."""
+# ------------------------------------------------------------------------------------------ CPU baselines
+def host_info():
+    import torch
+    info = {"threads": torch.get_num_threads(), "host_cpus": os.cpu_count()}
+    try:
+        out = subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout
+        for line in out.splitlines():
+            k, _, v = line.partition(":")
+            if k.strip() in ("Model name", "Socket(s)", "Core(s) per socket", "Thread(s) per core"):
+                info[k.strip()] = v.strip()
+    except (OSError, subprocess.SubprocessError):
+        pass
+    return info
+
+
+def _cpu_rows(rows, seq):
+    import torch
+    g = torch.Generator().manual_seed(1)
+    iq = (torch.randn(rows, seq, 2, generator=g) * 0.25).clamp(-0.7, 0.7)
+    return iq, iq[:, 5:, :].contiguous()
+
+
+def _gen_state():
+    import torch
     from oracle import generator as og
     from oracle import steps as ost
     from dpd_amd.models import TDNNGeneratorQAT
-    rows = 256
-    g = torch.Generator().manual_seed(1)
-    iq = (torch.randn(rows, seq, 2, generator=g) * 0.25).clamp(-0.7, 0.7)
-    target = iq[:, 5:, :].contiguous()
     torch.manual_seed(0)
     params = {k: v for k, v in TDNNGeneratorQAT().state_dict().items() if k in og.PARAM_KEYS}
-    gs = ost.GenState(params)
-    ost.stage1_step(gs, iq, target, qat)
+    return ost.GenState(params)
+
+
+def _time_loop(fn, budget):
+    fn()
     t0, reps = time.perf_counter(), 0
-    while time.perf_counter() - t0 < 10.0:
-        ost.stage1_step(gs, iq, target, qat)
+    while time.perf_counter() - t0 < budget or reps == 0:
+        fn()
         reps += 1
-    dt = time.perf_counter() - t0
+    return reps, time.perf_counter() - t0
+
+
+def cpu_stage1(qat, seq, budget=6.0):
+    """The CPU oracle (vectorised torch fp32, all host threads given to the job) on a bounded sample."""
+    import torch
+    from oracle import steps as ost
+    rows = 256
+    iq, target = _cpu_rows(rows, seq)
+    gs = _gen_state()
+    reps, dt = _time_loop(lambda: ost.stage1_step(gs, iq, target, qat), budget)
     return {"value": rows * (seq - 5) * reps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{reps} Stage-1 steps (qat={'on' if qat else 'off'}) of {rows} rows x {seq} samples "
-                      f"({rows * (seq - 5)} outputs each) with oracle/steps.py, torch CPU fp32, ~10 s"}
+                      f"({rows * (seq - 5)} outputs each) with oracle/steps.py, torch CPU fp32, ~{budget:.0f} s"}
 
+
+def cpu_stage2(seq, budget=15.0):
+    import torch
+    from oracle import critic as oc
+    from oracle import steps as ost
+    from dpd_amd.models import Discriminator
+    rows = 64
+    iq, target = _cpu_rows(rows, seq)
+    gs = _gen_state()
+    torch.manual_seed(1)
+    ds = ost.CriticState(oc.layers_from_state_dict(Discriminator().state_dict()))
+    g = torch.Generator().manual_seed(2)
+    alphas = [torch.rand(rows, 1, 1, generator=g) for _ in range(5)]
+    reps, dt = _time_loop(lambda: ost.stage2_step(gs, ds, iq, target, target, alphas), budget)
+    return {"value": rows * (seq - 5) * reps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} Stage-2 CWGAN-GP steps (5 critic updates + generator update, qat=on) of {rows} rows x {seq} samples "
+                      f"({rows * (seq - 5)} outputs each) with oracle/steps.py, torch CPU fp32 autograd, ~{budget:.0f} s"}
+
+
+def cpu_q88(seq, budget=5.0):
+    import numpy as np
+    from oracle import q88 as oq
+    from oracle import fixed_point as ofp
+    rng = np.random.default_rng(0)
+    rows = 16
+    iq = rng.integers(-20000, 20000, size=(rows, seq, 2)).astype(np.int16)
+    w = [rng.integers(-3000, 3000, size=s).astype(np.int16) for s in ((32, 30), (32,), (16, 32), (16,), (2, 16), (2,))]
+    lut = ofp.tanh_lut().numpy().astype(np.int16)
+    reps, dt = _time_loop(lambda: oq.infer_rows(iq, *w, lut), budget)
+    return {"value": rows * (seq - 5) * reps / dt, "unit": "samples/s", "cores": 1, "kind": "port",
+            "sample": f"{reps} passes of {rows} rows x {seq} int16 samples with oracle/q88.py (numpy int64, one thread), ~{budget:.0f} s"}
+
+
+def cpu_gen_pa(seq, budget=5.0):
+    import torch
+    from oracle import generator as og
+    from oracle import pa as opa
+    rows = 256
+    iq, _ = _cpu_rows(rows, seq)
+    gs = _gen_state()
+    cre, cim = opa.init_coeffs()
+
+    def fn():
+        with torch.no_grad():
+            return opa.volterra_forward(og.gen_forward(iq, gs.p, qat=True), cre, cim)
+    reps, dt = _time_loop(fn, budget)
+    return {"value": rows * (seq - 5) * reps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} passes of QAT generator + PA twin over {rows} rows x {seq} samples with the vectorised oracle, ~{budget:.0f} s"}
+
+
+def cpu_gen_pa_literal(budget=6.0):
+    """The reference's own loop structure (one Python iteration per output sample in the tap assembly, the
+    triple loop of the memory polynomial) on 2^14 samples."""
+    import torch
+    from oracle import generator as og
+    from oracle import literal as ol
+    from oracle import pa as opa
+    rows, seq = 64, 261
+    iq, _ = _cpu_rows(rows, seq)
+    gs = _gen_state()
+    cre, cim = opa.init_coeffs()
+
+    def fn():
+        with torch.no_grad():
+            feat = ol.tap_assembly_loop(iq)
+            out = og.gen_forward(feat.reshape(-1, 30), gs.p, qat=True, pre_assembled=True).reshape(rows, seq - 5, 2)
+            return ol.volterra_forward_loop(out, cre, cim)
+    reps, dt = _time_loop(fn, budget)
+    return {"value": rows * (seq - 5) * reps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} passes of the literal loop form (per-sample tap loop, triple PA loop; oracle/literal.py) over {rows} rows x {seq} "
+                      f"samples = {rows * (seq - 5)} outputs, ~{budget:.0f} s"}
+
+
+def cpu_spectral(seq, budget=3.0):
+    import torch
+    from oracle import spectral as osp
+    rows = 1024
+    _, target = _cpu_rows(rows, seq)
+    pred = (target * 0.9).requires_grad_(True)
+
+    def fn():
+        pred.grad = None
+        osp.spectral_loss(pred, target)[0].backward()
+    reps, dt = _time_loop(fn, budget)
+    return {"value": rows * (seq - 5) * reps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} SpectralLoss forward + backward passes over {rows} rows x {seq - 5} samples with oracle/spectral.py, ~{budget:.0f} s"}
+
+
+CPU_BASELINES = {
+    "stage2": lambda a: cpu_stage2(a.seq), "stage1": lambda a: cpu_stage1(False, a.seq), "stage1_qat": lambda a: cpu_stage1(True, a.seq),
+    "q88": lambda a: cpu_q88(a.seq), "q88_stream": lambda a: cpu_q88(a.seq), "gen_pa": lambda a: cpu_gen_pa(a.seq),
+    "spectral": lambda a: cpu_spectral(a.seq),
+}
 
 RUNNERS = {
+    "stage2": run_stage2,
     "stage1": lambda c, a, s, w: run_stage1(c, a, False, s, w),
     "stage1_qat": lambda c, a, s, w: run_stage1(c, a, True, s, w),
-    "stage2": run_stage2, "q88": run_q88, "q88_stream": run_q88_stream, "gen_pa": run_gen_pa, "spectral": run_spectral,
+    "q88": run_q88, "q88_stream": run_q88_stream, "gen_pa": run_gen_pa,
+    "gen_pa_float": lambda c, a, s, w: run_gen_pa(c, a, s, w, qat=False),
+    "gen_pa_train": run_gen_pa_train, "spectral": run_spectral,
 }
 LABELS = {
     "stage1": "Stage-1 supervised MSE step: fused generator forward + MSE + backward, Adam; qat=off",
     "stage1_qat": "Stage-1 supervised MSE step with QAT on: 4 abs-max passes + fused forward/MSE/backward, Adam",
     "stage2": "Stage-2 CWGAN-GP step: 5 critic updates (Wasserstein + gradient penalty) + generator update with SpectralLoss; qat=on",
     "q88": "Q8.8 fixed-point DPD inference, int16 in/out",
-    "q88_stream": "Q8.8 fixed-point DPD inference over a resident int16 stream, chunk by chunk (value = rate per chunk pass)",
-    "gen_pa": "validation chain: QAT generator forward + PA digital twin",
+    "q88_stream": "Q8.8 fixed-point DPD inference over a resident int16 stream, chunk by chunk",
+    "gen_pa": "validation chain: QAT generator forward + PA digital twin (4 abs-max passes, then one fused kernel)",
+    "gen_pa_float": "validation chain: float generator forward + PA digital twin in one kernel",
+    "gen_pa_train": "generator -> PA twin with fused backward: MSE on the PA output, generator gradients, Adam; qat=on",
     "spectral": "SpectralLoss forward + backward",
 }
+EXTRAS = ("stage1", "stage1_qat", "q88", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral")
+DTYPE = {"q88": "int16", "q88_stream": "int16", "stage2": "f32 (critic hidden-layer products: bf16 x 3-way split, fp32 accumulate)"}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     ctx = Ctx(args)
+    if args.gpus != ctx.world and ctx.rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {ctx.world} rank(s); reporting n_gpus={ctx.world}", file=sys.stderr)
     dt, roof, aux = RUNNERS[args.workload](ctx, args, args.steps, args.warmup)
     res = None
     if ctx.rank == 0:
         res = {
             "metric": METRIC, "value": ctx.n_local * ctx.world * args.steps / dt, "unit": "samples/s", "n_gpus": ctx.world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "int16" if args.workload.startswith("q88") else "f32",
+            "scaling": "strong" if ctx.strong else "weak", "vs_baseline": None, "dtype": DTYPE.get(args.workload, "f32"),
             "data": "synthetic",
-            "config": {"workload": LABELS[args.workload], "name": args.workload, "rows_per_gpu": args.rows,
-                       "seq_len": args.seq, "samples_per_gpu": ctx.n_local, "parallelism": f"dp{ctx.world}"},
+            "config": {"workload": LABELS[args.workload], "name": args.workload, "rows_per_gpu": ctx.rows,
+                       "seq_len": args.seq, "samples_per_gpu_per_step": ctx.n_local, "optimiser_steps_per_step": ctx.micro,
+                       "parallelism": f"dp{ctx.world}"},
             "roofline": roof,
         }
+        if ctx.strong:
+            res["config"].update(global_samples=ctx.n_local * ctx.world, global_batch=ctx.rows * (args.seq - 5) * ctx.world)
         res.update(aux)
-    if args.extras:
+    if not args.no_extras and not ctx.strong:
         extra = {}
-        for name in RUNNERS:
-            if name == args.workload or name == "q88_stream":
+        for name in EXTRAS:
+            if name == args.workload:
                 continue
-            k = 2 if name == "stage2" else 5
-            d, r, a = RUNNERS[name](ctx, args, k, 1)
+            d, r, a = RUNNERS[name](ctx, args, 5, 2)
             if ctx.rank == 0:
-                extra[name] = {"value": ctx.n_local * ctx.world * k / d, "unit": "samples/s", "ms_per_step": d / k * 1e3,
-                               "steps": k, "workload": LABELS[name], "roofline": r, **a}
+                extra[name] = {"value": ctx.n_local * ctx.world * 5 / d, "unit": "samples/s", "ms_per_step": d / 5 * 1e3,
+                               "steps": 5, "workload": LABELS[name], "roofline": r, **a}
         if ctx.rank == 0:
             res["extra"] = extra
     if ctx.rank == 0:
-        if not args.no_cpu_baseline and ctx.world == 1 and args.workload in ("stage1", "stage1_qat"):
-            res["cpu_baseline"] = cpu_baseline_stage1(args.workload == "stage1_qat", args.seq)
+        if not args.no_cpu_baseline and ctx.world == 1:
+            res["host"] = host_info()
+            res["cpu_baseline"] = CPU_BASELINES[args.workload](args)
+            if "extra" in res:
+                for name in ("stage1", "stage1_qat", "q88", "gen_pa", "spectral"):
+                    if name in res["extra"]:
+                        res["extra"][name]["cpu_baseline"] = CPU_BASELINES[name](args)
+                if "gen_pa" in res["extra"]:
+                    res["extra"]["gen_pa"]["cpu_baseline_literal"] = cpu_gen_pa_literal()
         print(json.dumps(res), flush=True)
     if ctx.world > 1:
         ctx.dist.destroy_process_group()

@@ -152,6 +152,26 @@ int dpd_gen_pa_forward(const float *iq, int64_t B, int64_t S, const float *wq, f
                        const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
                        float *dpd_out, float *y, void *stream);
 
+/* Backward of that chain for an upstream gradient gy [B, S-5-M+1, 2] on the PA output: grads[1554] w.r.t.
+ * the generator parameters (VolterraPA.forward, models/pa_digital_twin.py:125-170, composed with
+ * TDNNGeneratorQAT.forward, models/tdnn_generator.py:412-456, under autograd; the output quantiser passes
+ * the gradient through unchanged, :68-71).  For B*(S-5) >= 4096, M == 5 and K <= 4 (the reference's PA)
+ * one kernel recomputes the forward and runs PA adjoint and generator backward per tile pair: neither the
+ * generator output nor its gradient goes through HBM, and dpd_workspace_bytes(0) suffices.  Other shapes
+ * run on the separate kernels and need dpd_workspace_bytes(B * (S-5)).  absmax as for dpd_gen_pa_forward. */
+int dpd_gen_pa_backward(const float *iq, int64_t B, int64_t S, const float *wq, float slope, int qat,
+                        const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
+                        const float *gy, float *grads, void *ws, size_t ws_bytes, void *stream);
+
+/* The same with the loss inside: loss[0] = mean((PA(G(iq)) - target)^2) over target [B, S-5-M+1, 2] and
+ * grads[1554] = its gradient; nothing else is written.  This is torch.nn.functional.mse_loss on
+ * PADigitalTwin.forward(generator(iq), add_noise=False) (models/pa_digital_twin.py:311-338) under autograd:
+ * the twin is a differentiable module, although the reference's own scripts chain the two modules for
+ * evaluation only (validate.py:91-119, demo/video_demo.py:221-248). */
+int dpd_gen_pa_mse_step(const float *iq, int64_t B, int64_t S, const float *target, const float *wq, float slope,
+                        int qat, const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
+                        float *grads, float *loss, void *ws, size_t ws_bytes, void *stream);
+
 /* ---------------------------------------------------------------- critic ---------------- */
 
 /* Spectral normalisation of the four critic layers (SpectralNormLinear, models/discriminator.py:28-42;
@@ -231,6 +251,20 @@ int dpd_spectral_terms_backward(const float *stats, const float *coef, const flo
  * qmin, qmax); out = q (dequant == 0) or q/scale (dequant != 0). */
 int dpd_quantize_fixed(const float *x, int64_t n, float scale, int bits, int is_signed, int dequant,
                        float *out, void *stream);
+
+/* QuantizedLinear.forward (utils/quantization.py:213-233): out [N, out] = fq_act(fq_act(x) fq_w(w)^T + bias)
+ * with fq(v) = clamp(rint(v * scale), qmin, qmax) / scale for the given scales and bit widths; bias (fp32,
+ * may be NULL) is not quantised.  The sum is formed exactly (fp64 over exact products), so for the Q8.8 /
+ * Q1.15 power-of-two scales the result is that of the integer datapath, independent of summation order. */
+int dpd_quantized_linear(const float *x, const float *w, const float *bias, int64_t N, int in_features,
+                         int out_features, float act_scale, int act_bits, int act_signed, float w_scale, int w_bits,
+                         int w_signed, float *out, void *stream);
+
+/* Its backward with the straight-through estimator of FakeQuantizeFunction (utils/quantization.py:164-173):
+ * gx [N, in] = gy fq_w(w), gw [out, in] = gy^T fq_act(x), gb [out] = column sums of gy; each may be NULL. */
+int dpd_quantized_linear_backward(const float *x, const float *w, const float *gy, int64_t N, int in_features,
+                                  int out_features, float act_scale, int act_bits, int act_signed, float w_scale,
+                                  int w_bits, int w_signed, float *gx, float *gw, float *gb, void *stream);
 
 /* fake_quantize with a data-derived scale (models/tdnn_generator.py:74-103): x [rows, cols];
  * per_row == 0: one scale for the tensor, else one per row (rows <= 65535).  absmax_out [1] or [rows]

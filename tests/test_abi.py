@@ -63,7 +63,7 @@ def test_argument_errors_without_gpu():
     assert lib.dpd_pa_forward(p, 1, 40, p, p, 9, 5, p, null) == 1
     lib.dpd_spectral_stats.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p,
                                        ctypes.c_void_p, ctypes.c_void_p]
-    assert lib.dpd_spectral_stats(p, p, 1, 100, p, p, null) == 1  # not a power of two
+    assert lib.dpd_spectral_stats(p, p, 1, 9000, p, p, null) == 1  # neither a power of two nor within the direct-DFT limit
     i16 = (ctypes.c_int16 * 1024)()
     q = ctypes.cast(i16, ctypes.c_void_p)
     lib.dpd_q88_int32_safe.argtypes = [ctypes.c_void_p] * 6

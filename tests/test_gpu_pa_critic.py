@@ -253,7 +253,7 @@ def test_chain_fused_vs_modules_vs_oracle(qat, shape):
     cmp(d_f, d_mod.cpu().numpy())
     scale = float(y_mod.abs().max())
     close(y_f, y_mod.cpu().numpy(), rtol=1e-5, atol=2e-6 * scale if not qat else 2e-4 * scale)
-    close(y_only, y_f.cpu().numpy(), rtol=0, atol=0)
+    close(y_only, y_f.detach().cpu().numpy(), rtol=0, atol=0)
     # oracle
     d_ref = og.gen_forward(iq, params, qat=qat)
     cre, cim = pa.pa_model.coeffs_real.cpu(), pa.pa_model.coeffs_imag.cpu()
