@@ -110,6 +110,26 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
         p[4 * SER_STRIDE] = e4;
     }
 }
+// One time point: derive its five series values and park them at position tau of the chunk's series.
+template <bool QAT>
+DEV void commit_point(float *ser, float2 v, int tau, QS s0) {
+    float e = sqrtf(v.x * v.x + v.y * v.y);
+    float e2 = e * e;
+    float e4 = e2 * e2;
+    if (QAT) {
+        v.x = fq16(v.x, s0);
+        v.y = fq16(v.y, s0);
+        e = fq16(e, s0);
+        e2 = fq16(e2, s0);
+        e4 = fq16(e4, s0);
+    }
+    float *p = ser + SER_BASE0 + tau;
+    p[0] = v.x;
+    p[SER_STRIDE] = v.y;
+    p[2 * SER_STRIDE] = e;
+    p[3 * SER_STRIDE] = e2;
+    p[4 * SER_STRIDE] = e4;
+}
 struct FwdWeights {
     float A1[2][8];   // W1 tile t, step s: lane (i, g) holds W1[16t + i][slot 4s + g]
     float A2[2][4];   // W2[i][16t + 4g + r]
@@ -242,11 +262,12 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                                                              int64_t cpr, int64_t n_chunks,
                                                              const float *__restrict__ wq, float slope,
                                                              float *__restrict__ absmax, float2 *__restrict__ out,
-                                                             PaArgs pa) {
+                                                             PaArgs pa, unsigned unit) {
     static_assert(!PA || DEPTH == 4, "the fused chain is a final forward");
     __shared__ float lds[WAVES][SER_WORDS];
     __shared__ float pa_re[PA ? 128 : 1], pa_im[PA ? 128 : 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the chunk walk below runs on the scalar unit
     float *ser = lds[wave];
     ser[ZERO_W + lane] = 0.f;
     ser[ONE_W + lane] = 1.f;
@@ -323,31 +344,56 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
     };
 #define PHASE() __builtin_amdgcn_sched_barrier(0)
 
-    // the chunk's 69 IQ points are loaded one chunk ahead; (row, position) advance by a fixed step
-    const int64_t stride = (int64_t)gridDim.x * WAVES;
-    int64_t chunk = (int64_t)blockIdx.x * WAVES + wave;
-    const int64_t step_rows = stride / cpr, step_pos = stride - step_rows * cpr;
-    int64_t row = chunk / cpr, pos = chunk - row * cpr;
-    ChunkIQ pre;
-    int64_t t0 = 0;
-    if (chunk < n_chunks) {
-        t0 = pos * chunk_step;
-        load_chunk_iq(pre, iq + row * S, t0, S, lane);
-    }
-    while (chunk < n_chunks) {
-        commit_series<QAT>(ser, pre, lane, s0);
-        const int64_t t0_cur = t0, row_cur = row;
-        chunk += stride;
-        row += step_rows;
-        pos += step_pos;
-        if (pos >= cpr) {
-            pos -= cpr;
-            ++row;
+    // A wave walks through units of `unit` consecutive chunks (units dealt round robin over the waves; all of
+    // this is scalar).  A chunk needs 69 time points; consecutive chunks of a row share the last
+    // H = 69 - chunk_step of them (the 5 taps of history, plus the M - 1 generator outputs the PA chain
+    // recomputes), and their five series values are moved inside LDS instead of being loaded and derived
+    // again: each lane then loads and derives exactly one new point per chunk, one chunk ahead.  Only the
+    // first chunk of a run (start of a unit or of a row) loads its H leading points as well.
+    const unsigned n_waves = gridDim.x * WAVES, cpr32 = (unsigned)cpr, n_chunks32 = (unsigned)n_chunks;
+    const int H = 69 - chunk_step;
+    unsigned chunk = (blockIdx.x * WAVES + wave) * unit, k_in_unit = 0;
+    unsigned row = chunk / cpr32, pos = chunk - row * cpr32;
+    bool fresh = true;                     // the current chunk starts a run
+    float2 pre = make_float2(0.f, 0.f), pre_h = make_float2(0.f, 0.f);
+    auto fetch = [&](unsigned r, unsigned ps, bool fr) {
+        const float2 *iqrow = iq + (int64_t)r * S;
+        const int64_t tb = (int64_t)ps * chunk_step;
+        pre = make_float2(0.f, 0.f);
+        if (lane < chunk_step && tb + H + lane < S) pre = iqrow[tb + H + lane];
+        if (fr) {
+            pre_h = make_float2(0.f, 0.f);
+            if (lane < H && tb + lane < S) pre_h = iqrow[tb + lane];
         }
-        if (chunk < n_chunks) {
-            t0 = pos * chunk_step;
-            load_chunk_iq(pre, iq + row * S, t0, S, lane);
+    };
+    if (chunk < n_chunks32) fetch(row, pos, true);
+    while (chunk < n_chunks32) {
+        if (fresh) {
+            if (lane < H) commit_point<QAT>(ser, pre_h, lane, s0);
+        } else {
+            for (int c = lane; c < 5 * H; c += 64) {
+                const int type = c / H, w0 = SER_BASE0 + SER_STRIDE * type + (c - type * H);
+                ser[w0] = ser[w0 + chunk_step];
+            }
         }
+        if (lane < chunk_step) commit_point<QAT>(ser, pre, H + lane, s0);
+        const int64_t t0_cur = (int64_t)pos * chunk_step, row_cur = row;
+        // next chunk of this wave
+        if (++k_in_unit < unit) {
+            chunk += 1;
+            fresh = ++pos == cpr32;
+            if (fresh) {
+                pos = 0;
+                ++row;
+            }
+        } else {
+            k_in_unit = 0;
+            chunk += 1 + (n_waves - 1) * unit;
+            row = chunk / cpr32;
+            pos = chunk - row * cpr32;
+            fresh = true;
+        }
+        if (chunk < n_chunks32) fetch(row, pos, fresh);
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
@@ -496,7 +542,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
                                                              float *__restrict__ slab, unsigned *__restrict__ queue,
                                                              PaBwdArgs pa) {
     __shared__ __attribute__((aligned(16))) float lds[WAVES * BWD_WORDS];   // static: addresses fold into the instructions
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: chunk, row and position arithmetic run on the scalar unit
     float *ser = lds + wave * BWD_WORDS;
     ser[ZERO_W + lane] = 0.f;
     ser[ONE_W + lane] = 1.f;
@@ -1004,6 +1051,12 @@ static int mfma_grid(int64_t n_chunks, int per_cu = 2) {
     return (int)blocks;
 }
 
+// consecutive chunks per unit of the forward walk: as many as keep every wave busy, at most a row's worth of 16
+static unsigned fwd_unit(int64_t n_chunks, unsigned grid) {
+    const int64_t per_wave = n_chunks / ((int64_t)grid * WAVES);
+    return (unsigned)(per_wave < 1 ? 1 : per_wave > 16 ? 16 : per_wave);
+}
+
 int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st) {
     const float2 *iq = reinterpret_cast<const float2 *>(p.x);
     if (p.qat && depth == 0) {
@@ -1018,11 +1071,13 @@ int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st)
         return DPD_OK;
     }
     const int64_t cpr = (p.L + CHUNK - 1) / CHUNK, n_chunks = cpr * p.B;
+    DPD_REQUIRE(n_chunks < ((int64_t)1 << 31) - 65536, DPD_ERR_SHAPE, "gen_forward: %lld chunks exceed the 32-bit chunk counter", (long long)n_chunks);
     const dim3 grid(mfma_grid(n_chunks, FWD_WAVES_PER_SIMD)), block(WAVES * 64);
+    const unsigned unit = fwd_unit(n_chunks, grid.x);
     float2 *o = reinterpret_cast<float2 *>(out);
     const PaArgs none{nullptr, nullptr, 0, 0, nullptr, 0};
 #define GO(Q, D) hipLaunchKernelGGL((k_gen_fwd_mfma<Q, D, false>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
-                                    p.slope, p.absmax, o, none)
+                                    p.slope, p.absmax, o, none, unit)
     if (!p.qat) GO(false, 4);
     else if (depth == 1) GO(true, 1);
     else if (depth == 2) GO(true, 2);
@@ -1038,15 +1093,17 @@ int gen_mfma_pa_forward(const GenProblem &p, const float *cre, const float *cim,
     const float2 *iq = reinterpret_cast<const float2 *>(p.x);
     const int64_t OL = p.L - M + 1, step = CHUNK - (M - 1);
     const int64_t cpr = (OL + step - 1) / step, n_chunks = cpr * p.B;
+    DPD_REQUIRE(n_chunks < ((int64_t)1 << 31) - 65536, DPD_ERR_SHAPE, "gen_pa_forward: %lld chunks exceed the 32-bit chunk counter", (long long)n_chunks);
     const dim3 grid(mfma_grid(n_chunks, FWD_WAVES_PER_SIMD)), block(WAVES * 64);
+    const unsigned unit = fwd_unit(n_chunks, grid.x);
     const PaArgs pa{cre, cim, K, M, reinterpret_cast<float2 *>(y), OL};
     float2 *o = reinterpret_cast<float2 *>(out);
     if (p.qat)
         hipLaunchKernelGGL((k_gen_fwd_mfma<true, 4, true>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, p.slope,
-                           p.absmax, o, pa);
+                           p.absmax, o, pa, unit);
     else
         hipLaunchKernelGGL((k_gen_fwd_mfma<false, 4, true>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, p.slope,
-                           p.absmax, o, pa);
+                           p.absmax, o, pa, unit);
     DPD_LAUNCH_CHECK();
     return DPD_OK;
 }

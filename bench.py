@@ -57,7 +57,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="stage2",
-                    choices=["stage2", "stage1", "stage1_qat", "q88", "q88_stream", "gen_pa", "gen_pa_train", "spectral"])
+                    choices=["stage2", "stage1", "stage1_qat", "q88", "q88_stream", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral"])
     ap.add_argument("--stream-chunks", type=int, default=32, help="q88_stream: chunks of --rows rows per step (32 x 2^24 = 2^29 samples)")
     ap.add_argument("--rows", type=int, default=16384)
     ap.add_argument("--seq", type=int, default=1029)
