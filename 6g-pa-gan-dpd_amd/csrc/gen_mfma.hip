@@ -84,6 +84,7 @@ DEV void load_chunk_iq(ChunkIQ &c, const float2 *__restrict__ iqrow, int64_t t0,
         if ((rep == 0 || lane < 5) && idx < S) c.p[rep] = iqrow[idx];
     }
 }
+DEV f32x4 fq16x4(f32x4 v, QS k);
 // Derive the five series from the loaded points and park them in LDS.
 template <bool QAT>
 DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
@@ -96,10 +97,8 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
         float e2 = e * e;
         float e4 = e2 * e2;
         if (QAT) {
-            v.x = fq16(v.x, s0);
-            v.y = fq16(v.y, s0);
-            e = fq16(e, s0);
-            e2 = fq16(e2, s0);
+            const f32x4 qv = fq16x4(f32x4{v.x, v.y, e, e2}, s0);
+            v.x = qv[0]; v.y = qv[1]; e = qv[2]; e2 = qv[3];
             e4 = fq16(e4, s0);
         }
         float *p = ser + SER_BASE0 + tau;
@@ -117,10 +116,8 @@ DEV void commit_point(float *ser, float2 v, int tau, QS s0) {
     float e2 = e * e;
     float e4 = e2 * e2;
     if (QAT) {
-        v.x = fq16(v.x, s0);
-        v.y = fq16(v.y, s0);
-        e = fq16(e, s0);
-        e2 = fq16(e2, s0);
+        const f32x4 qv = fq16x4(f32x4{v.x, v.y, e, e2}, s0);
+        v.x = qv[0]; v.y = qv[1]; e = qv[2]; e2 = qv[3];
         e4 = fq16(e4, s0);
     }
     float *p = ser + SER_BASE0 + tau;
@@ -180,7 +177,7 @@ DEV f32x4 mul4(f32x4 a, f32x4 b) {
     return f32x4{lo[0], lo[1], hi[0], hi[1]};
 }
 // quantise-dequantise of a quad, the arithmetic of fq16(float, QS) element by element with its three
-// multiplies and two FMAs packed: 4 VALU instructions per element instead of 6
+// multiplies and two FMAs packed: 3 VALU instructions per element instead of 6
 DEV f32x4 fq16x4(f32x4 v, QS k) {
     const f32x2 inv = {k.inv, k.inv}, sc = {k.s, k.s};
     f32x4 out;
@@ -191,8 +188,10 @@ DEV f32x4 fq16x4(f32x4 v, QS k) {
         asm("v_pk_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(h), "v"(inv));
         asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(t) : "v"(q0), "v"(sc), "v"(h));
         asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(q) : "v"(t), "v"(inv), "v"(q0));
-        q[0] = fminf(fmaxf(rintf(q[0]), -32768.0f), 32767.0f);
-        q[1] = fminf(fmaxf(rintf(q[1]), -32768.0f), 32767.0f);
+        // no clamp: the scale comes from the abs-max of these very values (or of a superset, after a max-reduce
+        // over ranks), so |v / s| <= 32767 up to one rounding and the nearest integer is within the 16-bit range
+        q[0] = rintf(q[0]);
+        q[1] = rintf(q[1]);
         asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(q), "v"(sc));
         out[2 * i] = r[0];
         out[2 * i + 1] = r[1];

@@ -28,6 +28,23 @@ def ofdm_rows(batch: int, seq_len: int, seed: int, device, peak: float = 0.7) ->
     return torch.view_as_real(x).to(torch.float32).contiguous()
 
 
+TEMPERATURE_C = {"cold": -20.0, "normal": 25.0, "hot": 70.0}   # the reference's three training variants (train.py:497-513)
+
+
+def apply_thermal_drift(y: torch.Tensor, temperature: float, reference_temp: float = 25.0) -> torch.Tensor:
+    """Thermal drift of a PA output signal [..., 2] on the device: the model of the reference's
+    apply_thermal_drift (train.py:92-126).  With dT = temperature - reference_temp: gain 1 - 0.005 dT / 10,
+    phase shift 0.003 dT / 10 rad, AM/AM compression 1 - (0.01 dT / 50) |y|^2; y' = y * gain * compression * e^(j phase)."""
+    dt = float(temperature) - float(reference_temp)
+    gain = 1.0 + (-0.005) * (dt / 10.0)
+    phase = 0.003 * (dt / 10.0)
+    a_amam = 0.01 * (dt / 50.0)
+    yc = torch.view_as_complex(y.to(torch.float32).contiguous())
+    env2 = yc.real ** 2 + yc.imag ** 2
+    out = yc * (gain * (1.0 - a_amam * env2)) * complex(math.cos(phase), math.sin(phase))
+    return torch.view_as_real(out).contiguous()
+
+
 def augment_rows(rows: torch.Tensor, strength: float = 0.1, seed: int = 0) -> torch.Tensor:
     """Training-time augmentation of IQ rows [B, S, 2] on the device, one random draw per row and effect.
 

@@ -12,7 +12,8 @@ OFDM-like clean rows pushed through the PA twin of the chosen temperature state 
 
 One process per GPU under torch.distributed.run: rows are sharded, every loss term is that of the
 global batch (parallel.py), gradients are all-reduced once per backward.  Metrics stay on the device
-and are read once per epoch.
+during training; validation reads its metrics once per validation batch (compute_metrics returns Python floats,
+as the reference's does).
 """
 import argparse
 import csv
@@ -71,20 +72,46 @@ def _read_iq_csv(path: Path) -> torch.Tensor:
     return torch.tensor([[float(r["I"]), float(r["Q"])] for r in rows], dtype=torch.float32)
 
 
-def measured_rows(data_dir: Path, split: str, seq_len: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
-    """(input rows [B, seq_len, 2] = PA output, target rows [B, seq_len-5, 2] = PA input), windows with 50 % overlap
-    (utils/dataset.py:230-287), normalised by 0.7 / max|u| (train.py:80-83)."""
+def window_rows(x: torch.Tensor, seq_len: int) -> torch.Tensor:
+    """Rows [B, seq_len, 2] of a stream [n, 2]: windows of seq_len = L + 5 samples that advance by L // 2 (50 % overlap),
+    (n - 5 - L) // (L // 2) of them -- start indices and count of DPDDataset._prepare_sequences
+    (utils/dataset.py:262-279) -- as one strided view made contiguous, without a Python loop."""
+    L = seq_len - 5
+    hop = max(L // 2, 1)
+    count = (x.shape[0] - 5 - L) // hop
+    if count < 1:
+        raise ValueError(f"{x.shape[0]} samples are too few for one row of {seq_len} (need more than {seq_len + hop - 1})")
+    return x.unfold(0, seq_len, hop)[:count].permute(0, 2, 1).contiguous()
+
+
+def measured_rows(data_dir: Path, split: str, seq_len: int, device, temp: str = "normal") -> Tuple[torch.Tensor, torch.Tensor]:
+    """(input rows [B, seq_len, 2] = PA output, target rows [B, seq_len-5, 2] = PA input), normalised by
+    0.7 / max|u| (train.py:80-83), windows as `window_rows`.  `temp`: 'normal' leaves the PA output as measured, 'cold' /
+    'hot' apply the thermal drift of -20 / 70 degrees C to it, 'all' stacks the three variants (train.py:497-513)."""
+    from .data import TEMPERATURE_C, apply_thermal_drift
     u = _read_iq_csv(data_dir / f"{split}_input.csv").to(device)
     y = _read_iq_csv(data_dir / f"{split}_output.csv").to(device)
     n = min(u.shape[0], y.shape[0])
     scale = 0.7 / torch.sqrt((u[:n] ** 2).sum(-1)).max()
     u, y = u[:n] * scale, y[:n] * scale
-    if n < seq_len:
-        raise ValueError(f"{split}: {n} samples are fewer than one row of {seq_len}")
-    hop = max((seq_len - 5) // 2, 1)
-    yr = y.unfold(0, seq_len, hop).permute(0, 2, 1).contiguous()     # strided view -> rows, no Python loop
-    ur = u.unfold(0, seq_len, hop).permute(0, 2, 1)[:, 5:, :].contiguous()
-    return yr, ur
+    ur = window_rows(u, seq_len)[:, 5:, :].contiguous()
+    states = ["cold", "normal", "hot"] if temp == "all" else [temp]
+    yr = torch.cat([window_rows(y if st == "normal" else apply_thermal_drift(y, TEMPERATURE_C[st]), seq_len) for st in states])
+    return yr, ur.repeat(len(states), 1, 1)
+
+
+def shard_equal(x: torch.Tensor, t: torch.Tensor, batch_size: int, world: int, rank: int):
+    """This rank's rows of a row set that every rank sees whole, and the batch size to use: the same number of
+    rows and the same batch size on every rank (rows beyond a multiple of world * batch are dropped), so that all
+    ranks run the same number of steps -- every step issues collectives, and a rank with one step more would wait
+    in them for ever -- and the mean over ranks of equal-sized local means is the global mean."""
+    n = x.shape[0]
+    if n < world:
+        raise ValueError(f"{n} rows cannot be split over {world} ranks")
+    batch = min(batch_size, n // world)
+    per_rank = (n // (world * batch)) * batch
+    lo = rank * per_rank
+    return x[lo:lo + per_rank], t[lo:lo + per_rank], batch
 
 
 def synthetic_rows(rows: int, seq_len: int, temp: str, seed: int, device) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -214,14 +241,13 @@ def main(argv=None) -> Dict[str, float]:
 
     if args.data_dir:
         d = Path(args.data_dir)
-        x_all, t_all = measured_rows(d, "train", args.seq_len, device)
-        lo, hi = dp.shard_rows(x_all.shape[0])
-        x_tr, t_tr = x_all[lo:hi], t_all[lo:hi]
+        x_all, t_all = measured_rows(d, "train", args.seq_len, device, args.temp)
+        x_tr, t_tr, batch = shard_equal(x_all, t_all, int(tr["batch_size"]), dp.world, dp.rank)
         x_va, t_va = measured_rows(d, "val" if (d / "val_output.csv").exists() else "train", args.seq_len, device)
     else:
         x_tr, t_tr = synthetic_rows(args.rows, args.seq_len, args.temp, 1234 + rank, device)
         x_va, t_va = synthetic_rows(max(args.rows // 8, 8), args.seq_len, args.temp, 99, device)
-    batch = min(int(tr["batch_size"]), x_tr.shape[0])
+        batch = min(int(tr["batch_size"]), x_tr.shape[0])
 
     torch.manual_seed(0)
     gen, disc = create_models(config, args.qat, device)
@@ -240,7 +266,7 @@ def main(argv=None) -> Dict[str, float]:
         ckpt_dir.mkdir(parents=True, exist_ok=True)
     start, best = 0, float("inf")
     if args.resume:
-        ck = torch.load(args.resume, map_location=device, weights_only=False)   # a file this harness wrote
+        ck = torch.load(args.resume, map_location=device, weights_only=True)    # tensors, numbers, lists and dicts only
         gen.load_state_dict(ck["generator_state_dict"])
         disc.load_state_dict(ck["discriminator_state_dict"])
         g_opt.load_state_dict(ck["g_optimizer_state_dict"])

@@ -4,6 +4,6 @@ from .spectral_loss import (  # noqa: F401
 )
 from .quantization import (  # noqa: F401
     FakeQuantizeFunction, Q88Inference, QuantizationConfig, QuantizedLinear, dequantize_from_fixed_point,
-    export_q88_weights, export_weights_binary, fake_quantize, fake_quantize_grad, generate_leaky_relu_params,
-    generate_tanh_lut, load_weights_binary, quantize_to_fixed_point,
+    export_q88_flat, export_q88_hex, export_q88_weights, export_weights_binary, fake_quantize, fake_quantize_grad, generate_leaky_relu_params,
+    Q88_BANK_OFFSETS, Q88_BANK_SIZE, generate_tanh_lut, load_weights_binary, quantize_to_fixed_point, to_q8_8,
 )

@@ -212,6 +212,52 @@ def export_q88_weights(generator) -> Dict[str, torch.Tensor]:
     return out
 
 
+def to_q8_8(values: torch.Tensor) -> torch.Tensor:
+    """clip(round_half_even(v * 256), -32768, 32767) as int16: the notebook's `to_q8_8` (training_colab.ipynb,
+    weight-export cell), which agrees with quantize_to_fixed_point(v, 256, 16)."""
+    return quantize_to_fixed_point(values, 256.0, 16).to(torch.int16)
+
+
+Q88_BANK_OFFSETS = {"fc1_weights": 0, "fc1_bias": 960, "fc2_weights": 992, "fc2_bias": 1504, "fc3_weights": 1520, "fc3_bias": 1552}
+Q88_BANK_SIZE = 1554
+
+
+def export_q88_flat(generator) -> torch.Tensor:
+    """One weight bank of the FPGA inference engine as int16 [1554] (host tensor): all six parameter tensors in Q8.8,
+    each flattened row-major ([out, in]), in the order and at the offsets of rtl/src/tdnn_generator.v:70-79
+    (FC1 weights 0, b1 960, FC2 weights 992, b2 1504, FC3 weights 1520, b3 1552)."""
+    parts = []
+    for fc in (generator.fc1, generator.fc2, generator.fc3):
+        parts += [to_q8_8(fc.weight.data).reshape(-1), to_q8_8(fc.bias.data).reshape(-1)]
+    flat = torch.cat(parts).cpu()
+    if flat.numel() != Q88_BANK_SIZE:
+        raise ValueError(f"the bank layout is that of the 30 -> 32 -> 16 -> 2 generator ({Q88_BANK_SIZE} values), got {flat.numel()}")
+    return flat
+
+
+def _hex_lines(q: torch.Tensor) -> bytes:
+    return "".join(f"{int(v) & 0xFFFF:04x}\n" for v in q.reshape(-1).tolist()).encode("ascii")
+
+
+def export_q88_hex(generator, out_dir: Union[str, Path]) -> Dict[str, Path]:
+    """The notebook's hex export (one 16-bit two's-complement word per line, four lower-case hex digits):
+    fc{1,2,3}_weights.hex and fc{1,2,3}_bias.hex as the notebook writes them, plus weights_q88.hex, the whole bank
+    of `export_q88_flat` in one file for $readmemh."""
+    out_dir = Path(out_dir)
+    out_dir.mkdir(parents=True, exist_ok=True)
+    flat = export_q88_flat(generator)
+    ends = sorted(Q88_BANK_OFFSETS.values()) + [Q88_BANK_SIZE]
+    written = {}
+    for name, off in Q88_BANK_OFFSETS.items():
+        path = out_dir / f"{name}.hex"
+        path.write_bytes(_hex_lines(flat[off:ends[ends.index(off) + 1]]))
+        written[name] = path
+    path = out_dir / "weights_q88.hex"
+    path.write_bytes(_hex_lines(flat))
+    written["bank"] = path
+    return written
+
+
 class Q88Inference:
     """Bit-exact fixed-point DPD: iq int16 Q1.15 [B, S, 2] -> int16 Q1.15 [B, S-5, 2]."""
 

@@ -59,10 +59,12 @@ def ema_scale(running: torch.Tensor, x: torch.Tensor, n_bits: int = 16, momentum
 
 def gen_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], slope: float = 0.2, qat: bool = False,
                 pre_assembled: bool = False, n_bits: int = 16, memory_depth: int = 5,
-                running: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
+                running: Optional[Dict[str, torch.Tensor]] = None,
+                absmax_out: Optional[Dict[str, torch.Tensor]] = None) -> torch.Tensor:
     """x: IQ rows [B, S, 2] (-> [B, S-M, 2]) or, if pre_assembled, features [N, 30] (-> [N, 2]).
 
     If `running` is given (training mode) it is updated in place with the seven EMA scales.
+    If `absmax_out` is given (QAT) it receives the per-tensor abs-max behind each of the seven quantiser scales.
     """
     if pre_assembled:
         f, shape = x, None
@@ -79,11 +81,15 @@ def gen_forward(x: torch.Tensor, p: Dict[str, torch.Tensor], slope: float = 0.2,
         def act_q(t, key):
             if running is not None:
                 running[key] = ema_scale(running[key], t, n_bits)
+            if absmax_out is not None:
+                absmax_out[key] = t.detach().abs().max()
             return fake_quant_dyn(t, n_bits)
 
         def w_q(w, key):
             if running is not None:
                 running[key] = ema_scale(running[key], w, n_bits)
+            if absmax_out is not None:
+                absmax_out[key] = w.detach().abs().max()
             return fake_quant_dyn(w, n_bits, per_row=True)
 
         xq = act_q(f, "input_quant")

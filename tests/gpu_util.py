@@ -21,16 +21,23 @@ def close(a, b, rtol=1e-5, atol=1e-6):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
-def close_q(a, b, frac=0.95):
-    """Fake-quantised tensors: every entry within one 16-bit step of the tensor's scale, and at least
-    `frac` of them equal to fp32 rounding (the scale itself may differ in its last bit, so a
-    bit-for-bit comparison is not meaningful across tanh / GEMM implementations)."""
+def close_q(a, b, frac=None):
+    """Fake-quantised tensors: every entry within one 16-bit step of the tensor's scale, and all but a few
+    equal to fp32 rounding.  A pre-activation that differs in its last bits between two GEMM summation
+    orders (or a tanh that differs by an ulp) can land on the other side of a rounding boundary and move an
+    entry by one whole step; measured on this suite: at most 3.1 % of a 128-entry tensor (4 entries), 0.4-1.1 %
+    of larger ones.  Allowed: 2 % of the entries, or 5 entries for small tensors.  The scales themselves are
+    compared with the oracle's separately (test_qat_scales_match_oracle)."""
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
     lsb = np.abs(b).max() / 32767
     assert np.abs(a - b).max() <= lsb + 1e-5 * np.abs(b).max(), (np.abs(a - b).max(), lsb)  # one step + fp32 tolerance on the scale
     same = np.abs(a - b) <= 2e-6 * np.abs(b) + 1e-9
-    assert same.mean() >= frac, same.mean()
+    import os
+    if os.environ.get("DPD_CLOSEQ_REPORT"):
+        print(f"close_q: n={a.size} equal fraction {same.mean():.6f} max|d|/lsb {np.abs(a - b).max() / lsb:.4f}")
+    allowed = max(5, int(np.ceil(0.02 * a.size))) if frac is None else int(np.floor((1 - frac) * a.size))
+    assert (~same).sum() <= allowed, ((~same).sum(), a.size)
 
 
 def ofdm_rows(B, S, seed, peak=0.7):

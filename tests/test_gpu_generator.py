@@ -174,3 +174,34 @@ def test_fused_mse_step_matches_autograd_path(dpd, qat):
                L.fptr(loss), wsp, wsn, impl, st)
         close(loss[0], ref_loss, rtol=1e-5)
         close(grads, ref_flat, rtol=3e-4, atol=2e-7)
+
+
+@pytest.mark.parametrize("impl", [1, 2])
+@pytest.mark.parametrize("shape", [(4, 69), (8, 1029), (70, 64)])
+def test_qat_scales_match_oracle(dpd, impl, shape):
+    """The seven abs-max values behind the quantiser scales (features, act1, act2, tanh output, W1, W2, W3) against
+    the oracle's: the feature and weight maxima bit for bit, the activation maxima to four units in the last place
+    of fp32 (a 30- or 32-term dot product summed in another order moves the largest pre-activation by that much;
+    measured: 0 to 3)."""
+    from oracle import generator as og
+    from dpd_amd.models import TDNNGeneratorQAT
+    B, S = shape
+    torch.manual_seed(21)
+    gen = TDNNGeneratorQAT()
+    with torch.no_grad():
+        for fc in (gen.fc1, gen.fc2, gen.fc3):
+            fc.bias.uniform_(-0.1, 0.1)
+    params = {k: v.clone() for k, v in gen.state_dict().items() if k in og.PARAM_KEYS}
+    gen = gen.to(DEV).train()
+    gen.kernel_impl = impl
+    iq = ofdm_rows(B, S, seed=S)
+    ref = {}
+    og.gen_forward(iq, params, qat=True, absmax_out=ref)
+    gen(iq.to(DEV))
+    got = gen._last_absmax.cpu().numpy()
+    keys = og.ACT_QUANT_KEYS + og.WEIGHT_QUANT_KEYS
+    for i, k in enumerate(keys):
+        want = float(ref[k])
+        ulps = abs(float(got[i]) - want) / np.spacing(np.float32(want))
+        limit = 0 if k in ("input_quant",) + tuple(og.WEIGHT_QUANT_KEYS) else 4
+        assert ulps <= limit, (k, float(got[i]), want, ulps)

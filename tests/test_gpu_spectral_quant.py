@@ -1,6 +1,6 @@
 """GPU parity of the spectral metrics/loss, the fixed-point primitives and the Q8.8 integer inference.
 Tolerances: dB metrics within 0.1 dB (asserted far tighter), loss scalars rel 1e-5, loss gradients
-rel 1e-3 of their scale; fixed-point and Q8.8 results bit-exact."""
+2e-6 of their largest entry; fixed-point and Q8.8 results bit-exact."""
 import os
 import tempfile
 
@@ -11,6 +11,11 @@ import torch
 from gpu_util import DEV, T, close, load_golden, ofdm_rows
 
 pytestmark = pytest.mark.gpu
+
+# Gradients of the spectral losses: absolute tolerance as a fraction of the largest entry.  Two fp32 transforms
+# of up to 4,096 points in different butterfly orders differ by a few 1e-7 of that (measured against an fp64
+# evaluation: HIP path 1.0-2.1e-7, the fp32 oracle 1.6-2.9e-7, one against the other up to 3.2e-7).
+GTOL = 2e-6
 
 
 def test_spectral_golden():
@@ -26,7 +31,7 @@ def test_spectral_golden():
             close(comps[k], g[f"L{n}_{k}"], rtol=1e-5, atol=1e-7)
         total.backward()
         ref = g[f"L{n}_dpred"]
-        close(pred.grad, ref, rtol=1e-3, atol=1e-3 * np.abs(ref).max())
+        close(pred.grad, ref, rtol=1e-5, atol=GTOL * np.abs(ref).max())
         p = pred.detach()
         assert np.abs(compute_evm(p, tgt).cpu().numpy() - g[f"L{n}_evm_db"]).max() < 1e-3
         close(compute_evm(p, tgt, return_db=False), g[f"L{n}_evm_lin"], rtol=1e-5)
@@ -51,17 +56,17 @@ def test_spectral_golden():
     close(total, g["clamp_total"], rtol=1e-5)
     close(comps["evm"], g["clamp_evm"], rtol=1e-5, atol=1e-7)
     total.backward()
-    close(pp.grad, g["clamp_dpred"], rtol=1e-3, atol=1e-3 * np.abs(g["clamp_dpred"]).max())
+    close(pp.grad, g["clamp_dpred"], rtol=1e-5, atol=GTOL * np.abs(g["clamp_dpred"]).max())
     p256 = T(g["L256_pred"]).requires_grad_(True)
     el = EVMLoss()(p256, tgt)
     close(el, g["evmloss"], rtol=1e-5)
     el.backward()
-    close(p256.grad, g["evmloss_d"], rtol=1e-3, atol=1e-3 * np.abs(g["evmloss_d"]).max())
+    close(p256.grad, g["evmloss_d"], rtol=1e-5, atol=GTOL * np.abs(g["evmloss_d"]).max())
     p256 = T(g["L256_pred"]).requires_grad_(True)
     al = ACPRLoss()(p256)
     close(al, g["acprloss"], rtol=1e-4)
     al.backward()
-    close(p256.grad, g["acprloss_d"], rtol=2e-3, atol=2e-3 * np.abs(g["acprloss_d"]).max())
+    close(p256.grad, g["acprloss_d"], rtol=1e-5, atol=GTOL * np.abs(g["acprloss_d"]).max())
 
 
 def test_band_masks_match_reference():
@@ -86,7 +91,7 @@ def test_spectral_vs_oracle_lengths(n, rows):
     total = SpectralLoss()(p, tgt.to(DEV))
     close(total, ref.detach(), rtol=2e-5)
     total.backward()
-    close(p.grad, rg, rtol=1e-3, atol=1e-3 * float(rg.abs().max()))
+    close(p.grad, rg, rtol=1e-5, atol=GTOL * float(rg.abs().max()))
 
 
 def test_spectral_other_lengths():

@@ -93,7 +93,7 @@ def test_training_harness_two_stage_and_resume(tmp_path):
             "--config", "", "--output-dir", str(out), "--temp", "all", "--qat"]
     m = main(args)
     assert all(np.isfinite(m[k]) for k in ("val_evm_db", "val_nmse_db", "val_l1", "train_loss")) and m["stage"] == 2
-    ck = torch.load(out / "latest.pth", map_location="cpu", weights_only=False)
+    ck = torch.load(out / "latest.pth", map_location="cpu", weights_only=True)
     assert set(ck) == {"epoch", "generator_state_dict", "discriminator_state_dict", "g_optimizer_state_dict",
                        "d_optimizer_state_dict", "best_evm", "config"}
     assert ck["epoch"] == 1 and (out / "best.pth").exists()
@@ -104,7 +104,7 @@ def test_training_harness_two_stage_and_resume(tmp_path):
     m2 = main(["--epochs", "3", "--stage1-epochs", "1", "--rows", "64", "--seq-len", "261", "--batch-size", "32",
                "--config", "", "--output-dir", str(out), "--resume", str(out / "latest.pth"), "--qat"])
     assert np.isfinite(m2["val_evm_db"])
-    assert torch.load(out / "latest.pth", map_location="cpu", weights_only=False)["epoch"] == 2
+    assert torch.load(out / "latest.pth", map_location="cpu", weights_only=True)["epoch"] == 2
 
 
 def test_augment_rows_distributions():

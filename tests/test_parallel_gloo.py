@@ -58,6 +58,22 @@ def _worker(rank, world, port, ret):
         # mean_ / sum_
         v = torch.tensor([float(rank + 1)])
         assert dp.mean_(v.clone()).item() == 1.5 and dp.sum_(v.clone()).item() == 3.0
+        # --- an odd number of rows: every rank must get the same number of rows, batch size and steps (each step
+        # issues collectives; a rank with one step more would wait in them for ever)
+        spec = importlib.util.spec_from_file_location("dpd_train", os.path.join(ROOT, "6g-pa-gan-dpd_amd", "train.py"))
+        trn = importlib.util.module_from_spec(spec); spec.loader.exec_module(trn)
+        rows = torch.arange(1023 * 2, dtype=torch.float32).reshape(1023, 1, 2)
+        x_loc, t_loc, batch = trn.shard_equal(rows, rows, 256, dp.world, dp.rank)
+        steps = len(range(0, x_loc.shape[0] - batch + 1, batch))
+        shape = torch.tensor([x_loc.shape[0], batch, steps], dtype=torch.float32)
+        assert torch.equal(dp.max_(shape.clone()), shape) and torch.equal(-dp.max_(-shape.clone()), shape)
+        assert steps == 1 and batch == 256 and x_loc.shape[0] == 256
+        first = dp.sum_(x_loc[0, 0, :1].clone())          # rank 0 starts at row 0, rank 1 at row 256: disjoint shards
+        assert first.item() == 0.0 + 256 * 2
+        for _ in range(steps):                            # one collective per step, as the training steps issue
+            dp.sum_(torch.ones(1))
+        x_small, _, b_small = trn.shard_equal(rows[:7], rows[:7], 256, dp.world, dp.rank)
+        assert x_small.shape[0] == 3 and b_small == 3
         ret[rank] = "ok"
     finally:
         dist.destroy_process_group()

@@ -527,9 +527,107 @@ def g11_q88():
          lut_idx=npy(idx).astype(np.int16), out_i16=i16(out))
 
 
+# ----------------------------------------------------------------------------- g12
+def _ref_functions(rel, names, extra_globals):
+    """Function (or method) definitions taken out of a reference file whose module-level imports cannot be
+    satisfied here (train.py wants tensorboard, utils/dataset.py wants h5py): the named `def`s are compiled
+    from the file's own syntax tree and run as they stand; nothing else of the file is executed."""
+    import ast
+    with open(os.path.join(REF, rel)) as f:
+        tree = ast.parse(f.read())
+    found = {}
+    for node in ast.walk(tree):
+        if isinstance(node, ast.FunctionDef) and node.name in names:
+            mod = ast.Module(body=[node], type_ignores=[])
+            ns = dict(extra_globals)
+            exec(compile(mod, os.path.join(REF, rel), "exec"), ns)
+            found[node.name] = ns[node.name]
+    assert set(found) == set(names), (names, list(found))
+    return found
+
+
+def g12_data():
+    """Data path: CSV loading + normalisation (train.py:55-89), thermal drift (train.py:92-126) and the 50 %-overlap
+    windows of DPDDataset._prepare_sequences (utils/dataset.py:230-287) on a 1,500-row slice of the test split."""
+    import contextlib
+    import types
+    from pathlib import Path
+    import pandas as pd
+    n = 1500
+    tmp = Path(tempfile.mkdtemp())
+    for kind in ("input", "output"):
+        pd.read_csv(os.path.join(REF, "data", f"test_{kind}.csv"), nrows=n).to_csv(tmp / f"test_{kind}.csv", index=False)
+    from torch.utils.data import TensorDataset
+    fns = _ref_functions("train.py", ["load_measured_data", "apply_thermal_drift"], dict(np=np, pd=pd, Path=Path, torch=torch, TensorDataset=TensorDataset))
+    with contextlib.redirect_stdout(io.StringIO()):
+        u, y = fns["load_measured_data"](tmp, "test")
+    arrays = dict(csv_input=pd.read_csv(tmp / "test_input.csv").values.astype(np.float64),
+                  csv_output=pd.read_csv(tmp / "test_output.csv").values.astype(np.float64),
+                  u=np.stack([u.real, u.imag], -1).astype(np.float32), y=np.stack([y.real, y.imag], -1).astype(np.float32))
+    for t in (-20.0, 25.0, 70.0):
+        d = fns["apply_thermal_drift"](y, t)
+        arrays[f"drift_{int(t)}"] = np.stack([d.real, d.imag], -1).astype(np.float32)
+    meth = _ref_functions("utils/dataset.py", ["_prepare_sequences", "_apply_thermal_drift"], dict(np=np))
+    for L in (256, 100):
+        ds = types.SimpleNamespace(memory_depth=5, sequence_length=L, temp_state="normal", normalize=False,
+                                   pa_input_raw=u.copy(), pa_output_raw=y.copy(),
+                                   thermal_params={"normal": {"gain_drift": 0.0, "phase_drift_deg": 0, "am_am_scale": 1.0}})
+        ds._apply_thermal_drift = types.MethodType(meth["_apply_thermal_drift"], ds)
+        with contextlib.redirect_stdout(io.StringIO()):
+            meth["_prepare_sequences"](ds)
+        arrays[f"win{L}_input"] = np.stack([a for a, _ in ds.sequences]).astype(np.float32)
+        arrays[f"win{L}_target"] = np.stack([b for _, b in ds.sequences]).astype(np.float32)
+    save("g12_data", **arrays)
+
+
+# ----------------------------------------------------------------------------- g13
+def g13_q88_hex():
+    """Q8.8 hex export of the generator weights: the notebook's own `to_q8_8` and `export_to_hex` (training_colab.ipynb,
+    weight-export cell), taken out of the cell's syntax tree and run on seeded weights that include saturating values
+    and exact ties."""
+    import ast
+    import json
+    with open(os.path.join(REF, "training_colab.ipynb")) as f:
+        nb = json.load(f)
+    src = next("".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code" and "def to_q8_8" in "".join(c["source"]))
+    # the cell is notebook text with shell escapes elsewhere: parse only the two function definitions
+    fns = {}
+    for name in ("to_q8_8", "export_to_hex"):
+        start = src.index(f"def {name}(")
+        lines = src[start:].split("\n")
+        body = [lines[0]]
+        for ln in lines[1:]:
+            if ln.strip() and not ln.startswith((" ", "\t")):
+                break
+            body.append(ln)
+        ns = dict(np=np)
+        exec(compile(ast.parse("\n".join(body)), "training_colab.ipynb", "exec"), ns)
+        fns[name] = ns[name]
+    torch.manual_seed(1313)
+    g = TDNNGeneratorQAT()
+    with torch.no_grad():
+        g.fc1.weight[0, :4] = torch.tensor([130.0, -129.5, 127.998, -128.0])         # saturation
+        g.fc1.weight[1, :4] = torch.tensor([0.5, 1.5, 2.5, -0.5]) / 256               # ties
+        g.fc2.bias.copy_(torch.linspace(-0.3, 0.3, 16))
+        g.fc3.bias.copy_(torch.tensor([0.001953125, -0.005859375]))                     # 0.5 / 256, -1.5 / 256
+    arrays = sd_np(g, "sd__")
+    tmp = tempfile.mkdtemp()
+    for i, fc in ((1, g.fc1), (2, g.fc2), (3, g.fc3)):
+        for kind, t in (("weights", fc.weight), ("bias", fc.bias)):
+            q = fns["to_q8_8"](t.detach().numpy())
+            path = os.path.join(tmp, f"fc{i}_{kind}.hex")
+            # numpy 2 refuses `int16 & 0xFFFF` (the notebook ran under numpy 1, which widened): hand the same values over as int64
+            fns["export_to_hex"](q.astype(np.int64), path)
+            arrays[f"fc{i}_{kind}_q"] = q
+            arrays[f"fc{i}_{kind}_hex"] = np.frombuffer(open(path, "rb").read(), dtype=np.uint8)
+    save("g13_q88_hex", **arrays)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
     for fn in (g1_taps, g2_float_gen, g3_qat_gen, g4_fixed_point, g5_pa, g6_critic, g7_wgan_gp, g8_spectral,
-               g9_csv_chain, g10_steps, g11_q88):
+               g9_csv_chain, g10_steps, g11_q88, g12_data, g13_q88_hex):
+        if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
+            continue
         fn()
