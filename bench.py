@@ -180,7 +180,7 @@ def pmc_bytes(key):
     """HBM bytes per launch of a kernel from the rocprofv3 counter passes recorded under profiles/
     (TCC_EA read and write requests converted to bytes as the microarchitecture guide prescribes).  The counters cannot
     be read from inside this process; the figures apply to the default shape only."""
-    for name in ("r2_pmc.json", "r1_stage1_pmc.json"):
+    for name in ("r2_pmc_stage2.json", "r2_pmc_extras.json", "r1_stage1_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
