@@ -30,6 +30,7 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
 static int g_critic_impl = 0;
 extern int g_gen_deterministic;
 extern int g_critic_deterministic;
+extern int g_chain_carry;
 static bool critic_use_mfma(int64_t N) { return g_critic_impl == 2 || (g_critic_impl == 0 && N >= 1024); }
 
 extern "C" int dpd_set_option(const char *name, int value) {
@@ -44,6 +45,10 @@ extern "C" int dpd_set_option(const char *name, int value) {
     }
     if (__builtin_strcmp(name, "critic_deterministic") == 0 && (value == 0 || value == 1)) {
         g_critic_deterministic = value;
+        return DPD_OK;
+    }
+    if (__builtin_strcmp(name, "chain_carry") == 0 && value >= 0 && value <= 2) {
+        g_chain_carry = value;
         return DPD_OK;
     }
     dpd_set_error("set_option: unknown option %s or bad value %d", name, value);

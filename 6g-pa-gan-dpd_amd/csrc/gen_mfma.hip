@@ -256,29 +256,48 @@ struct PaArgs {
     float2 *y;                // [B, L - M + 1]
     int64_t OL;
 };
-template <bool QAT, int DEPTH, bool PA>
+// PAV: 0 no PA twin; 1 PA twin with run-time K and M (coefficients in LDS); 2 and 3 the reference's twin, K = 4 odd
+// orders and M = 5 taps: loops unrolled, the 40 coefficients in scalar registers, polynomial and complex product on
+// packed FMAs.  3 ("carry"): a wave walks whole rows (unit == chunks per row), chunks do not overlap: the last M - 1
+// generator outputs of a chunk stay in LDS for the next chunk of the row, whose lanes then evaluate the PA outputs
+// t0 - 4 .. t0 + 59.  No generator output is computed twice; the host picks it when the rows fill the waves evenly.
+template <bool QAT, int DEPTH, int PAV>
 __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
                                                              int64_t cpr, int64_t n_chunks,
                                                              const float *__restrict__ wq, float slope,
                                                              float *__restrict__ absmax, float2 *__restrict__ out,
                                                              PaArgs pa, unsigned unit) {
+    constexpr bool PA = PAV != 0, PAF = PAV >= 2, CARRY = PAV == 3;
     static_assert(!PA || DEPTH == 4, "the fused chain is a final forward");
     __shared__ float lds[WAVES][SER_WORDS];
-    __shared__ float pa_re[PA ? 128 : 1], pa_im[PA ? 128 : 1];
+    __shared__ float pa_re[PAV == 1 ? 128 : 1], pa_im[PAV == 1 ? 128 : 1];
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the chunk walk below runs on the scalar unit
     float *ser = lds[wave];
     ser[ZERO_W + lane] = 0.f;
     ser[ONE_W + lane] = 1.f;
-    if (PA) {
+    if (PAV == 1) {
         for (int i = threadIdx.x; i < pa.K * pa.M; i += WAVES * 64) {
             pa_re[i] = pa.cre[i];
             pa_im[i] = pa.cim[i];
         }
         __syncthreads();
     }
-    const int chunk_step = PA ? CHUNK - (pa.M - 1) : CHUNK;   // outputs a chunk advances by
-    float2 *const ybuf = reinterpret_cast<float2 *>(ser + TG_W);   // PA: the chunk's generator outputs
+    f32x2 pac[PAF ? 4 : 1][PAF ? 5 : 1];   // (re, im) of coefficient [k][m], uniform: scalar registers
+    if constexpr (PAF) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int m = 0; m < 5; ++m) {
+                pac[k][m][0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pa.cre[k * 5 + m])));
+                pac[k][m][1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pa.cim[k * 5 + m])));
+            }
+    }
+    const int chunk_step = CARRY ? CHUNK : PAF ? CHUNK - 4 : PA ? CHUNK - (pa.M - 1) : CHUNK;   // outputs a chunk advances by
+    // PA: the chunk's generator outputs (carry: behind the last four of the row's previous chunk)
+    float2 *const ybuf = reinterpret_cast<float2 *>(ser + TG_W);
+    constexpr int YB0 = CARRY ? 4 : 0;
+    static_assert(TG_W + 2 * (CHUNK + 4) <= SER_WORDS, "room for the carried outputs");
     FwdWeights w;
     load_fwd_weights(w, wq, j, g);
     int boff[8];
@@ -426,9 +445,9 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                     asm volatile("" : "+v"(u0), "+v"(u1));   // see the note on folded swap results in the backward kernel
                     const float2 yy = make_float2(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1));
                     if (PA) {
-                        if (!odd) ybuf[32 * p + 16 * (g >> 1) + j] = yy;
+                        if (!odd) ybuf[YB0 + 32 * p + 16 * (g >> 1) + j] = yy;
                         // generator outputs in the overlap belong to the next chunk of the row
-                        const bool mine = t < t0_cur + chunk_step || t0_cur + chunk_step >= pa.OL;
+                        const bool mine = CARRY || t < t0_cur + chunk_step || t0_cur + chunk_step >= pa.OL;
                         if (out && !odd && t < L && mine) out[row_cur * L + t] = yy;
                     } else {
                         if (out && !odd && t < L) out[row_cur * L + t] = yy;
@@ -440,7 +459,31 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                 V1(B, vB);
             }
         }
-        if (PA) {
+        if constexpr (PAF) {
+            __builtin_amdgcn_wave_barrier();
+            const int64_t n = t0_cur - YB0 + lane;               // PA output of this lane
+            if (lane < chunk_step && n >= 0 && n < pa.OL) {
+                const f32x2 *const yb = reinterpret_cast<const f32x2 *>(ybuf);
+                f32x2 acc = {0.f, 0.f};
+#pragma unroll
+                for (int m = 0; m < 5; ++m) {
+                    const f32x2 v = yb[lane + 4 - m];
+                    const float pw = __builtin_fmaf(v[1], v[1], v[0] * v[0]);
+                    const f32x2 pw2 = {pw, pw};
+                    f32x2 P = __builtin_elementwise_fma(pac[3][m], pw2, pac[2][m]);   // (Re, Im) of the tap polynomial, Horner in |u|^2
+                    P = __builtin_elementwise_fma(P, pw2, pac[1][m]);
+                    P = __builtin_elementwise_fma(P, pw2, pac[0][m]);
+                    // acc += v * P (complex): (v.x P.re, v.x P.im) then (-v.y P.im, v.y P.re)
+                    acc = __builtin_elementwise_fma(f32x2{v[0], v[0]}, P, acc);
+                    acc = __builtin_elementwise_fma(f32x2{-v[1], v[1]}, f32x2{P[1], P[0]}, acc);
+                }
+                pa.y[row_cur * pa.OL + n] = make_float2(acc[0], acc[1]);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if constexpr (CARRY) {
+                if (lane < 4) ybuf[lane] = ybuf[CHUNK + lane];
+            }
+        } else if (PA) {
             __builtin_amdgcn_wave_barrier();
             const int64_t n = t0_cur + lane;                     // PA output of this lane
             if (lane < chunk_step && n < pa.OL) {
@@ -1075,7 +1118,7 @@ int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st)
     const unsigned unit = fwd_unit(n_chunks, grid.x);
     float2 *o = reinterpret_cast<float2 *>(out);
     const PaArgs none{nullptr, nullptr, 0, 0, nullptr, 0};
-#define GO(Q, D) hipLaunchKernelGGL((k_gen_fwd_mfma<Q, D, false>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
+#define GO(Q, D) hipLaunchKernelGGL((k_gen_fwd_mfma<Q, D, 0>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, \
                                     p.slope, p.absmax, o, none, unit)
     if (!p.qat) GO(false, 4);
     else if (depth == 1) GO(true, 1);
@@ -1087,22 +1130,34 @@ int gen_mfma_forward(const GenProblem &p, int depth, float *out, hipStream_t st)
 }
 
 // Fused chain generator -> PA twin; out (generator output) may be NULL.  K * M <= 128, M <= 16.
+int g_chain_carry = 2;         // dpd_set_option("chain_carry", 0 off / 1 on / 2 automatic)
+
 int gen_mfma_pa_forward(const GenProblem &p, const float *cre, const float *cim, int K, int M, float *out, float *y,
                         hipStream_t st) {
     const float2 *iq = reinterpret_cast<const float2 *>(p.x);
-    const int64_t OL = p.L - M + 1, step = CHUNK - (M - 1);
-    const int64_t cpr = (OL + step - 1) / step, n_chunks = cpr * p.B;
-    DPD_REQUIRE(n_chunks < ((int64_t)1 << 31) - 65536, DPD_ERR_SHAPE, "gen_pa_forward: %lld chunks exceed the 32-bit chunk counter", (long long)n_chunks);
-    const dim3 grid(mfma_grid(n_chunks, FWD_WAVES_PER_SIMD)), block(WAVES * 64);
-    const unsigned unit = fwd_unit(n_chunks, grid.x);
+    const int64_t OL = p.L - M + 1;
+    // whole rows per wave without overlap between chunks ("carry") when the rows fill the resident waves evenly
+    // (and there are enough of them to fill the chip); otherwise chunks of 64 - (M - 1) outputs that overlap
+    bool carry = false;
+    if (K == 4 && M == 5 && g_chain_carry != 0) {
+        const int64_t waves = (int64_t)mfma_grid(p.B, FWD_WAVES_PER_SIMD) * WAVES;
+        const int64_t rows_per_wave = (p.B + waves - 1) / waves;
+        carry = g_chain_carry == 1 || (p.B >= 2048 && 10 * p.B >= 9 * rows_per_wave * waves);
+    }
+    const int64_t step = carry ? CHUNK : CHUNK - (M - 1), rowlen = carry ? p.L : OL;
+    const int64_t cpr = (rowlen + step - 1) / step, n_chunks = cpr * p.B;
+    DPD_REQUIRE(n_chunks < ((int64_t)1 << 31) - 65536 && cpr < ((int64_t)1 << 31), DPD_ERR_SHAPE,
+                "gen_pa_forward: %lld chunks exceed the 32-bit chunk counter", (long long)n_chunks);
+    const dim3 grid(mfma_grid(carry ? p.B : n_chunks, FWD_WAVES_PER_SIMD)), block(WAVES * 64);
+    const unsigned unit = carry ? (unsigned)cpr : fwd_unit(n_chunks, grid.x);
     const PaArgs pa{cre, cim, K, M, reinterpret_cast<float2 *>(y), OL};
     float2 *o = reinterpret_cast<float2 *>(out);
-    if (p.qat)
-        hipLaunchKernelGGL((k_gen_fwd_mfma<true, 4, true>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, p.slope,
-                           p.absmax, o, pa, unit);
-    else
-        hipLaunchKernelGGL((k_gen_fwd_mfma<false, 4, true>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, p.slope,
-                           p.absmax, o, pa, unit);
+#define GO(Q, V) hipLaunchKernelGGL((k_gen_fwd_mfma<Q, 4, V>), grid, block, 0, st, iq, p.S, p.L, cpr, n_chunks, p.wq, p.slope, \
+                                    p.absmax, o, pa, unit)
+    if (carry)            { if (p.qat) GO(true, 3); else GO(false, 3); }
+    else if (K == 4 && M == 5) { if (p.qat) GO(true, 2); else GO(false, 2); }
+    else                  { if (p.qat) GO(true, 1); else GO(false, 1); }
+#undef GO
     DPD_LAUNCH_CHECK();
     return DPD_OK;
 }

@@ -55,7 +55,11 @@ int dpd_version(void);
  * makes its gradients bitwise reproducible from run to run (default 0: chunks are handed out first
  * come, first served, ~3 % faster, gradients reproducible to fp32 summation order).
  * "critic_deterministic": the same choice for the MFMA critic backward and gradient-penalty kernels
- * (default 0: tiles first come, first served, ~4 % faster; 1: fixed order, bitwise reproducible). */
+ * (default 0: tiles first come, first served, ~4 % faster; 1: fixed order, bitwise reproducible).
+ * "chain_carry": how dpd_gen_pa_forward walks the rows when K = 4 and M = 5.  1 = every wave takes whole rows and
+ * carries the last four generator outputs of a chunk over to the next, so no output is computed twice; 0 = chunks of 60
+ * PA outputs that overlap by four generator outputs (any wave can take any chunk); 2 (default) = 1 when the batch has
+ * enough rows to fill the waves evenly, else 0.  The results agree to fp32 rounding (same arithmetic per output). */
 int dpd_set_option(const char *name, int value);
 
 /* Scratch size in bytes for the ws-taking entry points: dpd_workspace_bytes(0) suffices for every

@@ -222,11 +222,21 @@ def test_critic_ragged_sizes_vs_oracle(n, critic_impl):
 
 
 # ------------------------------------------------------------------ fused generator -> PA chain
+@pytest.fixture(params=[0, 1], ids=["overlap", "carry"])
+def chain_carry(request):
+    """Both row walks of the fused chain forward: chunks that overlap by M - 1 generator outputs, and whole rows
+    per wave with the last M - 1 outputs of a chunk carried over to the next (the default picks by batch shape)."""
+    from dpd_amd import _lib as L
+    L.call("dpd_set_option", b"chain_carry", request.param)
+    yield request.param
+    L.call("dpd_set_option", b"chain_carry", 2)
+
+
 @pytest.mark.parametrize("qat", [False, True])
-@pytest.mark.parametrize("shape", [(8, 1029), (5, 901), (3, 2000), (70, 64), (2, 37)])
-def test_chain_fused_vs_modules_vs_oracle(qat, shape):
-    """dpd_pa_chain (one kernel for >= 4096 samples, chunks overlapping by M - 1 generator outputs;
-    two-kernel fallback below) against generator module -> PA module and against the oracle."""
+@pytest.mark.parametrize("shape", [(8, 1029), (5, 901), (3, 2000), (70, 64), (2, 37), (33, 133), (9, 517)])
+def test_chain_fused_vs_modules_vs_oracle(qat, shape, chain_carry):
+    """dpd_pa_chain (one kernel for >= 4096 samples, two-kernel fallback below) against generator module ->
+    PA module and against the oracle."""
     from oracle import generator as og, pa as opa
     from dpd_amd.models import TDNNGeneratorQAT, PADigitalTwin, dpd_pa_chain
     B, S = shape
