@@ -334,7 +334,32 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
             t.a1 = mfma4(w.A1[1][s], b, t.a1);
         }
     };
-    auto V1 = [&](Tile &t, bool valid) {
+    // Abs-max passes end in the activation whose scale they produce.  |LeakyReLU(z)| = max(z, -slope z) for
+    // slope >= 0 and z -> slope z is monotonic, so the abs-max of the activations is max(max z, |slope min z|):
+    // the pass tracks the extremes of the raw sums (two three-operand instructions per pair of values) and
+    // applies the activation once per wave at the end.  zmax / zmin start at 0: a batch never has fewer values.
+    float zmax = 0.f, zmin = 0.f;
+    auto extremes = [&](const f32x4 &a, const f32x4 &b, bool valid, bool full) {
+        if (full) {            // wave-uniform: every sample of the tile lies inside the row
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                zmax = fmaxf(fmaxf(a[r], b[r]), zmax);
+                zmin = fminf(fminf(a[r], b[r]), zmin);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float x = valid ? a[r] : 0.f, y = valid ? b[r] : 0.f;
+                zmax = fmaxf(fmaxf(x, y), zmax);
+                zmin = fminf(fminf(x, y), zmin);
+            }
+        }
+    };
+    auto V1 = [&](Tile &t, bool valid, bool full) {
+        if (QAT && DEPTH == 1 && slope >= 0.f) {
+            extremes(t.a0, t.a1, valid, full);
+            return;
+        }
         const f32x4 x0 = lrelu4(t.a0, slope), x1 = lrelu4(t.a1, slope);
         t.ha = (QAT && DEPTH >= 2) ? fq16x4(x0, s1) : x0;
         t.hb = (QAT && DEPTH >= 2) ? fq16x4(x1, s1) : x1;
@@ -352,7 +377,12 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
             t.c1 = mfma4(w.A2[1][r], t.hb[r], t.c1);
         }
     };
-    auto V2 = [&](Tile &t, bool valid) {
+    auto V2 = [&](Tile &t, bool valid, bool full) {
+        if (QAT && DEPTH == 2 && slope >= 0.f) {
+            const f32x4 z = add4(t.c0, t.c1);
+            extremes(z, z, valid, full);
+            return;
+        }
         const f32x4 x = lrelu4(add4(t.c0, t.c1), slope);
         t.h2 = (QAT && DEPTH >= 3) ? fq16x4(x, s2) : x;
         if (QAT && DEPTH == 2) {
@@ -418,21 +448,22 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
             if (t0_cur + 32 * p >= L) break;      // wave-uniform: the wave stays convergent
             const int cA = 2 * p, cB = 2 * p + 1;
             const bool vA = (t0_cur + 16 * cA + j) < L, vB = (t0_cur + 16 * cB + j) < L;
+            const bool fA = t0_cur + 16 * cA + 16 <= L, fB = t0_cur + 16 * cB + 16 <= L;
             Tile A, B;
             S1(A, cA);
             PHASE();
             S1(B, cB);
-            V1(A, vA);
+            V1(A, vA, fA);
             PHASE();
             if (DEPTH >= 2) {
                 S2(A);
-                V1(B, vB);
+                V1(B, vB, fB);
                 PHASE();
                 S2(B);
-                V2(A, vA);
+                V2(A, vA, fA);
                 PHASE();
                 if (DEPTH >= 3) {
-                    V2(B, vB);
+                    V2(B, vB, fB);
                     // lane (g, j): output g & 1 of sample j of tile g >> 1
                     float y = tanh_f32(fc3_pair(w3p, b3k, A.h2, B.h2));
                     const int64_t t = t0_cur + 32 * p + 16 * (g >> 1) + j;
@@ -453,10 +484,10 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                         if (out && !odd && t < L) out[row_cur * L + t] = yy;
                     }
                 } else {
-                    V2(B, vB);
+                    V2(B, vB, fB);
                 }
             } else {
-                V1(B, vB);
+                V1(B, vB, fB);
             }
         }
         if constexpr (PAF) {
@@ -506,6 +537,11 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
     }
 #undef PHASE
     if (QAT && !PA) {
+        if (DEPTH <= 2 && slope >= 0.f) {
+            // the activation of the two extremes, with the arithmetic of lrelu4 (one rounding of slope * z)
+            // LeakyReLU(zmax) = zmax >= 0, LeakyReLU(zmin) = slope * zmin <= 0 (one rounding, as in lrelu4)
+            amax = fmaxf(zmax, fabsf(slope * zmin));
+        }
         amax = wave_max(amax);
         if (lane == 0) atomic_max_nonneg(absmax + DEPTH, amax);
     }

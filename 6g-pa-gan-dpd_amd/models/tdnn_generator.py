@@ -271,9 +271,24 @@ class TDNNGeneratorQAT(_GeneratorBase):
         weights would (used when a caller reuses the output instead of recomputing it)."""
         absmax = getattr(self, "_last_absmax", None)
         if absmax is not None:
-            # order of absmax: features, act1, act2, output, W1, W2, W3
-            for i, name in enumerate(self.ACT_QUANT + self.WEIGHT_QUANT):
-                getattr(self, name).observe(absmax[i])
+            self.observe_all(absmax)
+
+    def observe_all(self, absmax: torch.Tensor):
+        """The EMA update of every quantiser's running scale from the abs-max vector of a forward (order: features,
+        act1, act2, output, W1, W2, W3), all seven at once: the arithmetic of FakeQuantizeModule.observe element by
+        element, in six launches instead of thirty-five.  The buffers become views of one seven-element tensor."""
+        mods = [getattr(self, name) for name in self.ACT_QUANT + self.WEIGHT_QUANT]
+        m0 = mods[0]
+        if any(m.n_bits != m0.n_bits or m.momentum != m0.momentum for m in mods):
+            for i, m in enumerate(mods):
+                m.observe(absmax[i])
+            return
+        q_max = 2 ** (m0.n_bits - 1) - 1
+        scale = torch.clamp(absmax[:len(mods)], min=1e-8) / q_max
+        rs = torch.stack([m.running_scale for m in mods])
+        rs = (1 - m0.momentum) * rs + m0.momentum * scale
+        for m, r in zip(mods, rs.unbind(0)):
+            m.running_scale = r
 
     def get_quantized_weights(self) -> Dict[str, torch.Tensor]:
         weights = {}

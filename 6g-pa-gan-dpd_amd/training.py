@@ -65,19 +65,24 @@ class Stage1Step:
         L.call("dpd_gen_prepare_weights", *(L.fptr(p.detach()) for p in self.params), int(qat), L.fptr(self.wq),
                L.fptr(self.absmax), st)
         if qat:
-            if self.scratch_out is None or self.scratch_out.shape[0] != B or self.scratch_out.shape[1] != S - 5:
-                self.scratch_out = torch.empty(B, S - 5, 2, dtype=torch.float32, device=iq.device)
+            # the last pass writes the generator output unless the MFMA family runs it (IQ input of >= 4096
+            # samples): the step has no use for that output, so it is not written where it can be left out
+            mfma = self.impl == L.IMPL_MFMA or (self.impl == L.IMPL_AUTO and B * (S - 5) >= 4096)
+            outp = L.fptr(None)
+            if not mfma:
+                if self.scratch_out is None or self.scratch_out.shape[0] != B or self.scratch_out.shape[1] != S - 5:
+                    self.scratch_out = torch.empty(B, S - 5, 2, dtype=torch.float32, device=iq.device)
+                outp = L.fptr(self.scratch_out)
             for stage in range(4):
                 L.call("dpd_gen_absmax_pass", stage, L.fptr(iq), B, S, 0, L.fptr(self.wq), float(gen.leaky_slope),
-                       L.fptr(self.absmax), L.fptr(self.scratch_out), self.impl, st)
+                       L.fptr(self.absmax), outp, self.impl, st)
                 if self.absmax_sync is not None:
                     self.absmax_sync(self.absmax[stage:stage + 1])
         loss = self._core(iq, target, B, S, qat, st)
         if self.grad_sync is not None:
             self.grad_sync(self.grads)          # gradients and the loss in one buffer: one all-reduce
         if qat and gen.training:
-            for i, name in enumerate(gen.ACT_QUANT + gen.WEIGHT_QUANT):
-                getattr(gen, name).observe(self.absmax[i])
+            gen.observe_all(self.absmax)
         self.opt.step()
         return loss
 
@@ -100,6 +105,89 @@ class ChainStep(Stage1Step):
                int(qat), L.fptr(self.absmax), L.fptr(self.cre), L.fptr(self.cim), K, M, L.fptr(self.grads), L.fptr(loss),
                wsp, wsn, st)
         return loss
+
+
+class CriticUpdate:
+    """One critic update of the CWGAN-GP step without autograd in between: the three critic evaluations of
+    WassersteinLoss.discriminator_loss (real, fake, interpolate; each with its own spectral-norm power
+    iteration, in that order, as in the reference's models/discriminator.py:204-244) write their gradients
+    into rows of one buffer, the spectral-norm backward maps each row to the parameters, and the rows are
+    combined into one flat gradient whose slices are the parameters' .grad (one all-reduce, one fused Adam).
+    Same kernels and the same arithmetic per term as the autograd path, about a third of its launches."""
+
+    SIZES = [256, 64, 2048, 32, 512, 16, 16, 1]      # W1, b1, ..., W4, b4: the layout of the flat operand
+
+    def __init__(self, disc, opt, dp, gp_weight: float):
+        self.disc, self.opt, self.dp, self.gp_weight = disc, opt, dp, float(gp_weight)
+        self.layers = list(disc._layers())
+        dev = self.layers[0].weight_orig.device
+        n = L.CRITIC_NPARAM
+        f = dict(dtype=torch.float32, device=dev)
+        self.wb, self.uv, self.sigma = torch.empty(3, n, **f), torch.empty(3, 229, **f), torch.empty(3, 4, **f)
+        self.gwb, self.gpar = torch.empty(3, n, **f), torch.empty(3, n, **f)
+        self.total = torch.zeros(n, **f)
+        self.sums = torch.zeros(4, **f)                # sum D(real), sum D(fake), gradient penalty, unused
+        self.rownorm = None
+
+    @staticmethod
+    def supported(disc) -> bool:
+        from .models.discriminator import _SNLinearCore
+        layers = list(disc._layers())
+        return (disc.input_dim == 4 and list(disc.hidden_dims) == [64, 32, 16]
+                and all(isinstance(lin, _SNLinearCore) for lin in layers) and layers[0].weight_orig.is_cuda
+                and all(lin.weight_orig.dtype == torch.float32 for lin in layers))
+
+    def _bind_grads(self):
+        params = []
+        for lin in self.layers:
+            params += [lin.weight_orig, lin.bias]
+        for p, g in zip(params, torch.split(self.total, self.SIZES)):
+            if p.grad is None or p.grad.data_ptr() != g.data_ptr():
+                p.grad = g.view_as(p)
+
+    def __call__(self, real, fake, cond, alpha=None) -> torch.Tensor:
+        from .models.discriminator import _ptr_array
+        disc, dp = self.disc, self.dp
+        B = real.shape[0]
+        Lrow = real.shape[1] if real.dim() == 3 else 1
+        N = B * Lrow
+        dev = real.device
+        st = L.stream()
+        ws = _ptr_array([lin.weight_orig for lin in self.layers])
+        bs = _ptr_array([lin.bias for lin in self.layers])
+        us = _ptr_array([lin.weight_u for lin in self.layers])
+        vs = _ptr_array([lin.weight_v for lin in self.layers])
+        eps, slope, power = float(self.layers[0].eps), float(disc.leaky_slope), int(disc.training)
+        _, wsp, wsn = L.workspace(dev, N)
+        self.sums.zero_()
+        if alpha is None:
+            alpha = torch.rand(B, 1, device=dev)
+        if self.rownorm is None or self.rownorm.numel() != B:
+            self.rownorm = torch.empty(B, dtype=torch.float32, device=dev)
+        cond_c = L.as_f32(cond)
+        # d_loss = -(mean D(real) - mean D(fake)); every rank contributes its shard's mean / world
+        for k, (x, sign) in enumerate(((real, -1.0), (fake, 1.0))):
+            L.call("dpd_critic_sn_forward", ws, bs, us, vs, power, eps, L.fptr(self.wb[k]), L.fptr(self.uv[k]),
+                   L.fptr(self.sigma[k]), st)
+            L.call("dpd_critic_backward", L.fptr(L.as_f32(x)), L.fptr(cond_c), N, L.fptr(self.wb[k]), slope, L.c_p(0),
+                   sign / (N * dp.world), L.fptr(self.gwb[k]), L.c_p(0), L.fptr(self.sums[k:k + 1]), wsp, wsn, st)
+            L.call("dpd_critic_sn_backward", ws, L.fptr(self.gwb[k]), L.fptr(self.uv[k]), L.fptr(self.sigma[k]),
+                   L.fptr(self.gpar[k]), st)
+        L.call("dpd_critic_sn_forward", ws, bs, us, vs, power, eps, L.fptr(self.wb[2]), L.fptr(self.uv[2]),
+               L.fptr(self.sigma[2]), st)
+        L.call("dpd_critic_gp", L.fptr(L.as_f32(real)), L.fptr(L.as_f32(fake)), L.fptr(cond_c),
+               L.fptr(L.as_f32(alpha).reshape(-1)), B, Lrow, L.fptr(self.wb[2]), slope, L.fptr(self.sums[2:3]),
+               L.fptr(self.rownorm), L.fptr(self.gwb[2]), wsp, wsn, st)
+        L.call("dpd_critic_sn_backward", ws, L.fptr(self.gwb[2]), L.fptr(self.uv[2]), L.fptr(self.sigma[2]),
+               L.fptr(self.gpar[2]), st)
+        torch.add(self.gpar[0], self.gpar[1], out=self.total)
+        self.total.add_(self.gpar[2], alpha=self.gp_weight / dp.world)
+        self._bind_grads()
+        dp.sum_(self.total)
+        self.opt.step()
+        s = self.sums
+        d_total = ((s[1] - s[0]) / N + self.gp_weight * s[2]) / dp.world
+        return dp.sum_(d_total)
 
 
 class Stage2Step:
@@ -125,6 +213,8 @@ class Stage2Step:
         self.dp = dp or DataParallel()
         if self.dp.enabled:
             generator.absmax_sync = self.dp.max_
+        # critic updates without autograd between the kernels where the critic has the shape they are built for
+        self.critic_update = CriticUpdate(discriminator, self.d_opt, self.dp, gp_weight) if CriticUpdate.supported(discriminator) else None
 
     def _critic_loss(self, target, fake, cond, alpha):
         dev = target.device
@@ -160,10 +250,13 @@ class Stage2Step:
         fake = gen(iq)
         fake_d = fake.detach()
         for it in range(self.n_critic):
-            self.d_opt.zero_grad(set_to_none=True)
             if it > 0 and hasattr(gen, "repeat_observation"):
                 gen.repeat_observation()
             alpha = alphas[it] if alphas is not None else None
+            if self.critic_update is not None and target.dim() == 3:
+                info[f"d_total_{it}"] = self.critic_update(target, fake_d, cond, alpha)
+                continue
+            self.d_opt.zero_grad(set_to_none=True)
             d_total, d_info = self._critic_loss(target, fake_d, cond, alpha)
             d_total.backward()
             dp.sum_grads_(d_params)
