@@ -29,6 +29,26 @@ void dpd_set_error(const char *fmt, ...);
 
 static inline hipStream_t as_stream(void *s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Set-up that must happen once per GPU (function attributes belong to the device that is current when they are
+// set): first_use() is true the first time it is called with a given device current.  Two threads that race on
+// the first use of a device both see true; the set-up calls are idempotent.
+#include <atomic>
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> seen{0};
+    bool first_use(int *device) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+            *device = -1;
+            return true;              // unknown device: do the set-up every time
+        }
+        *device = dev;
+        return (seen.load(std::memory_order_acquire) >> dev & 1ull) == 0;
+    }
+    void mark(int device) {
+        if (device >= 0) seen.fetch_or(1ull << device, std::memory_order_release);
+    }
+};
+
 // Blocks for a grid-stride kernel: enough to fill 256 CUs several times over, never more than the work.
 static inline int grid_for(int64_t items, int per_block, int max_blocks = 256 * 8) {
     int64_t b = (items + per_block - 1) / per_block;

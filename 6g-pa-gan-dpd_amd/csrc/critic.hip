@@ -465,13 +465,14 @@ extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N,
     const int grid = grid_for(N, TPB, 1024);
     float *slab = reinterpret_cast<float *>(ws);
     constexpr size_t lds_bytes = (size_t)(C_NP + 3 + TPB * LP + TPB * RP) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;   // per device, not per process
+    int attr_dev;
+    if (attr_once.first_use(&attr_dev)) {
         DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_critic_bwd<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
         DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_critic_bwd<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     if (!grads) {   // input gradient only (generator update): no panel reduction, no slab
         hipLaunchKernelGGL(k_critic_bwd<false>, dim3(grid_for(N, TPB, 4096)), dim3(TPB), lds_bytes, st,
@@ -520,11 +521,12 @@ extern "C" int dpd_critic_gp(const float *real, const float *fake, const float *
     DPD_LAUNCH_CHECK();
     const int grid = grid_for(N, TPB, 1024);
     constexpr size_t lds_bytes = (size_t)(C_NP + 3 + TPB * LPG + TPB * RPG) * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static PerDeviceOnce attr_once;
+    int attr_dev;
+    if (attr_once.first_use(&attr_dev)) {
         DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_gp_bwd),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        attr_set = true;
+        attr_once.mark(attr_dev);
     }
     hipLaunchKernelGGL(k_gp_bwd, dim3(grid), dim3(TPB), lds_bytes, st, g, masks, rowc, N, L, wb, slope, slab);
     DPD_LAUNCH_CHECK();

@@ -923,8 +923,10 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
                                                                 const float *__restrict__ gscore, float gconst,
                                                                 float2 *__restrict__ gx, float *__restrict__ slab,
                                                                 float *__restrict__ score_sum, unsigned *__restrict__ queue) {
-    // (a static array above 64 KiB compiles and would save ~20 address additions per tile, but a launch with
-    // it never finished on the device: dynamic it stays)
+    // (dynamic: the size depends on WGRAD.  A static array above 64 KiB as such launches and completes on this
+    // part without any attribute -- scratch/ubench/static_lds_probe.hip -- so the one variant of this kernel
+    // that never finished with a static array failed for a reason of its own, which was not tracked down;
+    // that variant is gone)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // WGRAD: LDS_WORDS (> 64 KiB), else IMG_WORDS
     build_image(lds, wb);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
@@ -1364,13 +1366,14 @@ static int allow_big_lds(K kernel, size_t bytes) {
 constexpr size_t BIG_LDS = (size_t)LDS_WORDS * sizeof(float), IMG_LDS = (size_t)IMG_WORDS * sizeof(float);
 
 static int init_attrs() {
-    static bool done = false;
-    if (done) return DPD_OK;
+    static PerDeviceOnce once;        // the attribute is per device: a process that drives several GPUs sets it on each
+    int dev;
+    if (!once.first_use(&dev)) return DPD_OK;
     int rc = allow_big_lds(k_critic_bwd_mfma<true, true>, BIG_LDS);
     rc = rc ? rc : allow_big_lds(k_critic_bwd_mfma<true, false>, BIG_LDS);
     rc = rc ? rc : allow_big_lds(k_gp_c_mfma<true>, BIG_LDS);
     rc = rc ? rc : allow_big_lds(k_gp_c_mfma<false>, BIG_LDS);
-    if (rc == DPD_OK) done = true;
+    if (rc == DPD_OK) once.mark(dev);
     return rc;
 }
 
