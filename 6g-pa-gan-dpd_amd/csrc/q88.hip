@@ -54,6 +54,15 @@ DEV int envelope_q88(unsigned s) {
 // ceil((z - 2) / 5) = floor((z - 2) * 52429 / 2^18) + 1 (52429 / 2^18 = 1/5 + 1/1310720, exact for
 // |z| < 2^16), it is >= z there, and for z > 0 the same expression stays <= z: one max selects.
 DEV int lrelu_q(int z) { return max(z, (__mul24(z, 52429) + (262144 - 2 * 52429)) >> 18); }
+// The same for a z that has not been saturated yet (|z| < 2^16: what a 32-bit accumulator can leave after the
+// shift by 15).  Saturation and LeakyReLU commute except below -32768, where the saturated value gives
+// lrelu(-32768) = -6554: one three-operand max covers it.  The upper side is left to the saturating pack.
+DEV int lrelu_q_unsat(int z) {
+    const int t = (__mul24(z, 52429) + (262144 - 2 * 52429)) >> 18;
+    return max(max(z, t), -6554);
+}
+// two int32 -> two int16 with saturation, packed: one instruction (v_cvt_pk_i16_i32)
+DEV int pack2_sat(int lo, int hi) { return __builtin_bit_cast(int, __builtin_amdgcn_cvt_pk_i16(lo, hi)); }
 
 DEV int pack2(int lo, int hi) { return (lo & 0xffff) | (hi << 16); }
 
@@ -95,12 +104,13 @@ DEV void dense_q(const int *__restrict__ wp, const int *__restrict__ bp, const i
                 for (int k = 0; k < KP; ++k)
                     acc = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2_t, a[s][k]), __builtin_bit_cast(short2_t, w[k]),
                                                  acc, false);
-                r = sat16(rhe_shift(acc, 15));
+                // with the activation behind it the saturation moves into the pack of the pair (see lrelu_q_unsat)
+                r = ACT ? rhe_shift(acc, 15) : sat16(rhe_shift(acc, 15));
             }
             done[j + 2][s] = r;
             if (ACT) {
-                r = lrelu_q(r);
-                if (j & 1) z[s][j >> 1] = pack2(z[s][j >> 1], r);
+                r = lrelu_q_unsat(r);
+                if (j & 1) z[s][j >> 1] = pack2_sat(z[s][j >> 1], r);
                 else z[s][j >> 1] = r;
             } else {
                 z[s][j] = r;

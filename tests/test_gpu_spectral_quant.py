@@ -186,7 +186,12 @@ def test_q88_random_rows_and_extremes_vs_oracle():
     iq[1, 7] = (32767, -32768); iq[1, 8] = (-32768, -32768); iq[2, 9] = (1024, 1024)
     base = [g[k] for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
     big = [rng.integers(-32768, 32768, size=a.shape, dtype=np.int64).astype(np.int16) for a in base]
-    for ws, expect64 in ((base, False), (big, True)):
+    # biases at the ends of the int16 range: pre-activations beyond +-32768 (saturation on both sides, in both
+    # layers) while the weights stay small enough for the 32-bit proof
+    edge = [a.copy() for a in base]
+    edge[1][:4] = (32767, -32768, 32767, -32768)
+    edge[3][:4] = (32767, -32768, -32768, 32767)
+    for ws, expect64 in ((base, False), (edge, False), (big, True)):
         w = {k: T(a) for k, a in zip(("w1", "b1", "w2", "b2", "w3", "b3"), ws)}
         w["lut"] = T(g["lut"])
         eng = Q88Inference(w)
@@ -194,6 +199,8 @@ def test_q88_random_rows_and_extremes_vs_oracle():
         out = eng(T(iq)).cpu().numpy()
         ref = oq.infer_rows(iq, *ws, g["lut"])
         assert np.array_equal(out, ref)
+        if not expect64:      # the 64-bit kernel on the same weights
+            assert np.array_equal(Q88Inference(w, force_acc64=True)(T(iq)).cpu().numpy(), ref)
 
 
 def test_q88_export_from_generator():
