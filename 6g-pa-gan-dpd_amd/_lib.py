@@ -51,6 +51,7 @@ PROTOTYPES = {
     "dpd_fake_quantize_dynamic": [c_p, c_l, c_l, c_i, c_i, c_p, c_p, c_p],
     "dpd_q88_infer": [c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "dpd_q88_int32_safe": [c_p, c_p, c_p, c_p, c_p, c_p],
+    "dpd_q88_digits_fit": [c_p, c_p, c_p],
     "dpd_workspace_bytes": [c_l],
     "dpd_set_option": [ctypes.c_char_p, c_i],
     "dpd_last_error": [],

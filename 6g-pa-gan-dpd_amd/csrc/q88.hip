@@ -183,6 +183,228 @@ __global__ __launch_bounds__(TPB) void k_q88(const int *__restrict__ iq, int64_t
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------
+// Matrix-core form: the same integer contract on v_mfma_i32_16x16x64_i8, every int16 as two 8-bit digits.
+//   activation a = 256 ah + (al + 128),  ah = a >> 8 in [-128, 127],  al = (a & 255) - 128 in [-128, 127]
+//   weight     w = 256 wh + wl,          wl = (int8)(w & 255),        wh = (w - wl) >> 8 in [-128, 127] for w <= 32639
+//   sum a w = 65536 sum ah wh + 256 sum (ah wl + al wh) + sum al wl + 128 sum w
+// Three int32 accumulators per result tile (HH, X, LL), each far from overflow; the constant 128 sum_k w[j][k] joins the
+// bias (the start value of LL); the combination and everything behind it is the arithmetic of the VALU form.
+// The host checks the weight range (dpd_q88_digits_fit) and the 32-bit proof before it selects this form.
+//
+// Geometry as in the float generator kernels: a wave owns 64 consecutive outputs of a row (4 tiles of 16), products are
+// computed transposed (D = W X^T): lane (g, j) of a result holds neurons 4g..4g+3 of sample j, and the 16 bytes a lane
+// feeds into the next product are the digits of exactly the values it holds (the K order of the next layer's weight
+// image is chosen to match), so no value moves between lanes.  K = 64 = 4 lane groups x 16 bytes; groups 0, 1 carry
+// high digits, groups 2, 3 low digits (FC1), or bytes 0..7 high and 8..15 low digits of the lane's eight values (FC2).
+// FC1 operands: the five per-point series live in LDS as byte planes [digit][series][point]; the six taps of a series
+// are six consecutive bytes, fetched as aligned dwords and shifted into place with v_alignbyte_b32.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+constexpr int MW = 4;                 // waves per workgroup
+constexpr int PLANE = 96;             // bytes per digit plane: 69 points + the over-read of the last dword, multiple of 4
+constexpr int WAVE_LDS = 10 * PLANE;  // [digit 0..1][series 0..4]
+DEV i32x4 mfma_i8(i32x4 a, i32x4 b, i32x4 c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
+DEV int digit_lo(int w) { return (int)(signed char)(w & 0xff); }
+DEV int digit_hi(int w) { return (w - digit_lo(w)) >> 8; }
+// reference feature index (models/tdnn_generator.py:176-193) of (series, tap); series 0..4 = I, Q, |x|, |x|^2, |x|^4
+DEV int feature_index(int series, int tap) {
+    if (series == 0) return tap == 0 ? 0 : 20 + 2 * (tap - 1);
+    if (series == 1) return tap == 0 ? 1 : 21 + 2 * (tap - 1);
+    return 2 + 6 * (series - 2) + tap;
+}
+// FC1 slot of byte e in a lane of half h (0: lane groups 0 and 2, 1: groups 1 and 3): (series, tap), or series -1 for the
+// two padding bytes.  Bytes run over ascending points: tap = 5 - point offset.
+DEV void fc1_slot(int half, int e, int &series, int &tap) {
+    if (e < 6) { series = half ? 3 : 0; tap = 5 - e; }
+    else if (e < 12) { series = half ? 4 : 1; tap = 5 - (e - 6); }
+    else if (!half) { series = 2; tap = 5 - (e - 12); }
+    else if (e < 14) { series = 2; tap = 5 - (e - 12 + 4); }
+    else { series = -1; tap = 0; }
+}
+// one byte of a weight image: lanes / bytes that meet high activation digits (act_hi) or low ones
+DEV int image_byte(int w, bool act_hi, int variant) {   // variant 0: HH, 1: X, 2: LL
+    const int wl = digit_lo(w), wh = digit_hi(w);
+    if (variant == 0) return act_hi ? wh : 0;
+    if (variant == 1) return act_hi ? wl : wh;
+    return act_hi ? 0 : wl;
+}
+DEV int pack4(int b0, int b1, int b2, int b3) { return (b0 & 0xff) | ((b1 & 0xff) << 8) | ((b2 & 0xff) << 16) | ((unsigned)(b3 & 0xff) << 24); }
+
+struct Q88Weights {
+    const short *w1, *b1, *w2, *b2, *w3, *b3;
+};
+
+// epilogue of a result quad: combine the three accumulators, requantise, LeakyReLU (saturation rides on the pack)
+DEV void requant_act4(const i32x4 &hh, const i32x4 &x, const i32x4 &ll, int &p01, int &p23) {
+    int h[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // (modular arithmetic: a single term may pass 2^31, the sum is the true accumulator, which the host has bounded)
+        const int acc = (int)(((unsigned)hh[r] << 16) + (((unsigned)x[r] << 8) + (unsigned)ll[r]));
+        h[r] = lrelu_q_unsat(rhe_shift(acc, 15));
+    }
+    p01 = pack2_sat(h[0], h[1]);
+    p23 = pack2_sat(h[2], h[3]);
+}
+// digits of two packed int16 pairs (four values) -> four high-digit bytes, four low-digit bytes
+DEV void digits4(int p01, int p23, int &hi, int &lo) {
+    hi = __builtin_amdgcn_perm(p23, p01, 0x07050301u);                  // the upper byte of an int16 is a >> 8
+    lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080;     // (a & 255) - 128 as a signed byte
+}
+
+__global__ __launch_bounds__(MW * 64, 2) void k_q88_mfma(const int *__restrict__ iq, int64_t S, int64_t L, int64_t cpr,
+                                                         int64_t n_chunks, Q88Weights wt, const short *__restrict__ lut,
+                                                         int *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char planes[MW][WAVE_LDS];
+    __shared__ int s_lut[256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kb = lane >> 4;
+    s_lut[tid] = lut[tid];
+    unsigned char *pl = planes[wave];
+    for (int k = lane; k < WAVE_LDS / 4; k += 64) reinterpret_cast<int *>(pl)[k] = 0;
+    __syncthreads();
+
+    // ---- weight images and start values (once per wave)
+    const bool act_hi_lane = kb < 2;          // FC1: lane groups 0, 1 meet high activation digits
+    const int half = kb & 1;
+    i32x4 A1[2][3], A2[3], A3[3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) {
+            int by[16];
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                int series, tap;
+                fc1_slot(half, e, series, tap);
+                const int w = series >= 0 ? wt.w1[(16 * t + j) * 30 + feature_index(series, tap)] : 0;
+                by[e] = image_byte(w, act_hi_lane, v);
+            }
+            A1[t][v] = i32x4{pack4(by[0], by[1], by[2], by[3]), pack4(by[4], by[5], by[6], by[7]),
+                             pack4(by[8], by[9], by[10], by[11]), pack4(by[12], by[13], by[14], by[15])};
+        }
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        int by[16], bz[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ee = e & 7;
+            const int m2 = ee < 4 ? 4 * kb + ee : 16 + 4 * kb + (ee - 4);     // FC2 input neuron of this byte
+            by[e] = image_byte(wt.w2[j * 32 + m2], e < 8, v);
+            const int m3 = 4 * kb + (e & 3);                                   // FC3: bytes 0..3 high, 4..7 low, 8..15 unused
+            bz[e] = (e < 8 && j < 2) ? image_byte(wt.w3[j * 16 + m3], e < 4, v) : 0;
+        }
+        A2[v] = i32x4{pack4(by[0], by[1], by[2], by[3]), pack4(by[4], by[5], by[6], by[7]),
+                      pack4(by[8], by[9], by[10], by[11]), pack4(by[12], by[13], by[14], by[15])};
+        A3[v] = i32x4{pack4(bz[0], bz[1], bz[2], bz[3]), pack4(bz[4], bz[5], bz[6], bz[7]), 0, 0};
+    }
+    // start of the LL accumulators: (bias << 15) + 128 sum_k w[n][k] for the neurons 4 kb + r of each row tile
+    i32x4 c1[2], c2, c3;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int n = 16 * t + 4 * kb + r;
+            int sw = 0;
+            for (int k = 0; k < 30; ++k) sw += wt.w1[n * 30 + k];
+            c1[t][r] = ((int)wt.b1[n] << 15) + 128 * sw;
+        }
+        {
+            const int n = 4 * kb + r;
+            int sw = 0;
+            for (int k = 0; k < 32; ++k) sw += wt.w2[n * 32 + k];
+            c2[r] = ((int)wt.b2[n] << 15) + 128 * sw;
+        }
+        {
+            const int n = 4 * kb + r;
+            int sw = 0;
+            if (n < 2)
+                for (int k = 0; k < 16; ++k) sw += wt.w3[n * 16 + k];
+            c3[r] = n < 2 ? ((int)wt.b3[n] << 15) + 128 * sw : 0;
+        }
+    }
+    // FC1 operand gather: three runs of consecutive bytes, the same instruction sequence in every lane
+    const int digit = kb >> 1;
+    const int pA = (digit * 5 + (half ? 3 : 0)) * PLANE + j;
+    const int pB = (digit * 5 + (half ? 4 : 1)) * PLANE + j;
+    const int pC = (digit * 5 + 2) * PLANE + j + 4 * half;
+    const unsigned sh = j & 3;                 // the same for the three runs: plane bases and the half offset are multiples of 4
+    const unsigned char *qA = pl + (pA & ~3), *qB = pl + (pB & ~3), *qC = pl + (pC & ~3);
+    const i32x4 zero4 = {0, 0, 0, 0};
+
+    const int64_t n_waves = (int64_t)gridDim.x * MW;
+    for (int64_t chunk = (int64_t)blockIdx.x * MW + wave; chunk < n_chunks; chunk += n_waves) {
+        const int64_t row = chunk / cpr, t0 = (chunk - row * cpr) * 64;
+        const int *p = iq + row * S + t0;          // p[u]: point u of the chunk; output t uses points t .. t + 5
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int rep = 0; rep < 2; ++rep) {
+            const int u = lane + 64 * rep;
+            if (rep == 1 && lane >= 5) break;
+            const int v = (t0 + u < S) ? p[u] : 0;
+            const int i = (short)(v & 0xffff), q = v >> 16;
+            const unsigned ss = (unsigned)(i * i) + (unsigned)(q * q);
+            int f[5];
+            f[0] = sat16(rhe_shift(i, 7));
+            f[1] = sat16(rhe_shift(q, 7));
+            f[2] = envelope_q88(ss);
+            f[3] = (int)(((unsigned long long)ss + ((1u << 21) - 1) + ((ss >> 22) & 1u)) >> 22);
+            f[4] = (int)(((unsigned long long)ss * ss + (1ull << 51)) >> 52);
+#pragma unroll
+            for (int s5 = 0; s5 < 5; ++s5) {
+                pl[s5 * PLANE + u] = (unsigned char)(f[s5] >> 8);
+                pl[(5 + s5) * PLANE + u] = (unsigned char)((f[s5] & 0xff) ^ 0x80);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (t0 + 16 * c >= L) break;           // wave-uniform
+            // ---- FC1 operand
+            const int *a = reinterpret_cast<const int *>(qA + 16 * c), *b = reinterpret_cast<const int *>(qB + 16 * c);
+            const int *cc = reinterpret_cast<const int *>(qC + 16 * c);
+            const int a0 = a[0], a1 = a[1], a2 = a[2], b0 = b[0], b1 = b[1], b2 = b[2], c0 = cc[0], c1w = cc[1];
+            const int A03 = __builtin_amdgcn_alignbyte(a1, a0, sh), A47 = __builtin_amdgcn_alignbyte(a2, a1, sh);
+            const int B03 = __builtin_amdgcn_alignbyte(b1, b0, sh), B47 = __builtin_amdgcn_alignbyte(b2, b1, sh);
+            const int C03 = __builtin_amdgcn_alignbyte(c1w, c0, sh);
+            const i32x4 X1 = {A03, (int)__builtin_amdgcn_perm(B03, A47, 0x05040100u), (int)__builtin_amdgcn_perm(B47, B03, 0x05040302u), C03};
+            // ---- FC1: two row tiles x (HH, X, LL)
+            int p1[4];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const i32x4 hh = mfma_i8(A1[t][0], X1, zero4), xx = mfma_i8(A1[t][1], X1, zero4), ll = mfma_i8(A1[t][2], X1, c1[t]);
+                requant_act4(hh, xx, ll, p1[2 * t], p1[2 * t + 1]);
+            }
+            int h0, l0, h1, l1;
+            digits4(p1[0], p1[1], h0, l0);           // bytes 0..3 / 8..11: neurons 4 kb + r of row tile 0
+            digits4(p1[2], p1[3], h1, l1);           // bytes 4..7 / 12..15: row tile 1
+            const i32x4 X2 = {h0, h1, l0, l1};
+            // ---- FC2
+            int p2[2];
+            {
+                const i32x4 hh = mfma_i8(A2[0], X2, zero4), xx = mfma_i8(A2[1], X2, zero4), ll = mfma_i8(A2[2], X2, c2);
+                requant_act4(hh, xx, ll, p2[0], p2[1]);
+            }
+            int h2, l2;
+            digits4(p2[0], p2[1], h2, l2);
+            const i32x4 X3 = {h2, l2, 0, 0};
+            // ---- FC3 and the output table: rows 0, 1 of the result = registers 0, 1 of lane group 0
+            const i32x4 hh = mfma_i8(A3[0], X3, zero4), xx = mfma_i8(A3[1], X3, zero4), ll = mfma_i8(A3[2], X3, c3);
+            int o[2];
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int acc = (int)(((unsigned)hh[r] << 16) + (((unsigned)xx[r] << 8) + (unsigned)ll[r]));
+                const int z = sat16(rhe_shift(acc, 15));
+                int idx = rhe_shift((z + 1024) * 255, 11);
+                idx = min(max(idx, 0), 255);
+                o[r] = s_lut[idx];
+            }
+            const int64_t t = t0 + 16 * c + j;
+            if (kb == 0 && t < L) out[row * L + t] = pack2(o[0], o[1]);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int16_t *w1, const int16_t *b1,
@@ -190,6 +412,7 @@ extern "C" int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int1
                              const int16_t *lut, int acc64, int16_t *out, void *stream) {
     DPD_REQUIRE(((iq && out) || B == 0) && w1 && b1 && w2 && b2 && w3 && b3 && lut, DPD_ERR_INVALID_ARG, "q88_infer: null pointer");
     DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
+    DPD_REQUIRE(acc64 >= 0 && acc64 <= 2, DPD_ERR_INVALID_ARG, "q88_infer: mode %d not in 0..2", acc64);
     auto aligned4 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 3) == 0; };
     DPD_REQUIRE(aligned4(iq) && aligned4(out) && aligned4(w1) && aligned4(b1) && aligned4(w2) && aligned4(b2) &&
                     aligned4(w3) && aligned4(b3),
@@ -201,7 +424,13 @@ extern "C" int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int1
     const int *iqp = reinterpret_cast<const int *>(iq);
     int *op = reinterpret_cast<int *>(out);
     auto dw = [](const int16_t *q) { return reinterpret_cast<const int *>(q); };
-    if (acc64)
+    if (acc64 == 2) {
+        const int64_t cpr = (L + 63) / 64, n_chunks = B * cpr;
+        int64_t blocks = (n_chunks + MW - 1) / MW;
+        if (blocks > 256 * 4) blocks = 256 * 4;
+        const Q88Weights wt{w1, b1, w2, b2, w3, b3};
+        hipLaunchKernelGGL(k_q88_mfma, dim3((unsigned)blocks), dim3(MW * 64), 0, st, iqp, S, L, cpr, n_chunks, wt, lut, op);
+    } else if (acc64)
         hipLaunchKernelGGL((k_q88<true>), grid, block, 0, st, iqp, S, L, segs_per_row, n_segs, dw(w1), dw(b1), dw(w2),
                            dw(b2), dw(w3), dw(b3), lut, op);
     else
@@ -209,6 +438,15 @@ extern "C" int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int1
                            dw(b2), dw(w3), dw(b3), lut, op);
     DPD_LAUNCH_CHECK();
     return DPD_OK;
+}
+
+// 1 if every weight splits into two signed 8-bit digits (w <= 32639: the high digit of a larger weight would be 128).
+extern "C" int dpd_q88_digits_fit(const int16_t *h_w1, const int16_t *h_w2, const int16_t *h_w3) {
+    if (!h_w1 || !h_w2 || !h_w3) return 0;
+    for (int k = 0; k < 32 * 30; ++k) if (h_w1[k] > 32639) return 0;
+    for (int k = 0; k < 16 * 32; ++k) if (h_w2[k] > 32639) return 0;
+    for (int k = 0; k < 2 * 16; ++k) if (h_w3[k] > 32639) return 0;
+    return 1;
 }
 
 // Interval propagation over the three layers: worst-case |accumulator| from the weights alone.

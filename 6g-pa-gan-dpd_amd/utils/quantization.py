@@ -261,11 +261,19 @@ def export_q88_hex(generator, out_dir: Union[str, Path]) -> Dict[str, Path]:
 class Q88Inference:
     """Bit-exact fixed-point DPD: iq int16 Q1.15 [B, S, 2] -> int16 Q1.15 [B, S-5, 2]."""
 
-    def __init__(self, weights: Dict[str, torch.Tensor], force_acc64: bool = False):
+    MODE_VALU32, MODE_VALU64, MODE_MATRIX = 0, 1, 2
+
+    def __init__(self, weights: Dict[str, torch.Tensor], force_acc64: bool = False, force_valu: bool = False):
+        """Three kernels give the same bits; the fastest one the weights allow is picked: the int8 matrix cores (every
+        int16 as two 8-bit digits) when 32-bit accumulation is provably exact and every weight is <= 32639, the integer
+        VALU with 32-bit accumulators when only the proof holds, with 64-bit accumulators otherwise.  `force_acc64` /
+        `force_valu` select the slower kernels (tests)."""
         self.w = {k: v.contiguous() for k, v in weights.items()}
         host = [self.w[k].cpu().contiguous() for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
         safe = L.lib().dpd_q88_int32_safe(*(L.c_p(t.data_ptr()) for t in host))
+        fit = L.lib().dpd_q88_digits_fit(*(L.c_p(host[i].data_ptr()) for i in (0, 2, 4)))
         self.acc64 = bool(force_acc64 or not safe)
+        self.mode = self.MODE_VALU64 if self.acc64 else (self.MODE_MATRIX if (fit and not force_valu) else self.MODE_VALU32)
 
     def __call__(self, iq: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`out` (optional, int16 [B, S-5, 2], contiguous) receives the result in place of a new tensor: a
@@ -283,5 +291,5 @@ class Q88Inference:
             raise RuntimeError(f"out must be a contiguous int16 tensor of shape {(B, S - 5, 2)}")
         i16 = torch.int16
         L.call("dpd_q88_infer", L.fptr(x, i16), B, S, *(L.fptr(self.w[k], i16) for k in ("w1", "b1", "w2", "b2", "w3", "b3")),
-               L.fptr(self.w["lut"], i16), int(self.acc64), L.fptr(out, i16), L.stream())
+               L.fptr(self.w["lut"], i16), int(self.mode), L.fptr(out, i16), L.stream())
         return out

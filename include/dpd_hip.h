@@ -279,8 +279,11 @@ int dpd_fake_quantize_dynamic(const float *x, int64_t rows, int64_t cols, int pe
 /* Bit-exact Q8.8 inference: iq int16 Q1.15 [B,S,2] -> out int16 Q1.15 [B,S-5,2].
  * Weights int16 Q1.15 (w1 [32,30], w2 [16,32], w3 [2,16]), biases int16 Q8.8, accumulators Q9.23,
  * requantisation round-half-even with saturation (utils/quantization.py:88-120, :213-256),
- * tanh through the 256-entry table of generate_tanh_lut (:365-393).  acc64 != 0 forces 64-bit
- * accumulators; acc64 == 0 requires dpd_q88_int32_safe() to hold for the weights. */
+ * tanh through the 256-entry table of generate_tanh_lut (:365-393).  acc64 selects the kernel, all three
+ * give the same bits: 1 = integer VALU with 64-bit accumulators (any weights); 0 = integer VALU with 32-bit
+ * accumulators (v_dot2_i32_i16), requires dpd_q88_int32_safe() to hold for the weights; 2 = the int8 matrix cores
+ * (every int16 as two 8-bit digits, three int32 accumulators per product), requires dpd_q88_int32_safe() and
+ * dpd_q88_digits_fit(). */
 int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int16_t *w1, const int16_t *b1,
                   const int16_t *w2, const int16_t *b2, const int16_t *w3, const int16_t *b3,
                   const int16_t *lut, int acc64, int16_t *out, void *stream);
@@ -289,6 +292,10 @@ int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int16_t *w1, co
  * every input, 0 otherwise. */
 int dpd_q88_int32_safe(const int16_t *h_w1, const int16_t *h_b1, const int16_t *h_w2, const int16_t *h_b2,
                        const int16_t *h_w3, const int16_t *h_b3);
+
+/* Host-side check for mode 2 of dpd_q88_infer: 1 if every weight is <= 32639 (splits into two signed 8-bit
+ * digits), 0 otherwise. */
+int dpd_q88_digits_fit(const int16_t *h_w1, const int16_t *h_w2, const int16_t *h_w3);
 
 #ifdef __cplusplus
 }
