@@ -52,12 +52,15 @@ PROTOTYPES = {
     "dpd_q88_infer": [c_p, c_l, c_l, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p],
     "dpd_q88_int32_safe": [c_p, c_p, c_p, c_p, c_p, c_p],
     "dpd_q88_digits_fit": [c_p, c_p, c_p],
+    "dpd_q88_matrix_image_bytes": [],
+    "dpd_q88_matrix_prepare": [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p],
+    "dpd_q88_matrix_infer": [c_p, c_l, c_l, c_p, c_p, c_p, c_p],
     "dpd_workspace_bytes": [c_l],
     "dpd_set_option": [ctypes.c_char_p, c_i],
     "dpd_last_error": [],
     "dpd_version": [],
 }
-_RESTYPES = {"dpd_workspace_bytes": c_sz, "dpd_last_error": ctypes.c_char_p}
+_RESTYPES = {"dpd_workspace_bytes": c_sz, "dpd_q88_matrix_image_bytes": c_sz, "dpd_last_error": ctypes.c_char_p}
 
 
 def lib():

@@ -202,6 +202,9 @@ __global__ __launch_bounds__(TPB) void k_q88(const int *__restrict__ iq, int64_t
 // are six consecutive bytes, fetched as aligned dwords and shifted into place with v_alignbyte_b32.
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int MW = 4;                 // waves per workgroup
+#ifndef Q88_MFMA_WAVES
+#define Q88_MFMA_WAVES 3              // resident waves per SIMD (register budget 168)
+#endif
 constexpr int PLANE = 96;             // bytes per digit plane: 69 points + the over-read of the last dword, multiple of 4
 constexpr int WAVE_LDS = 10 * PLANE;  // [digit 0..1][series 0..4]
 DEV i32x4 mfma_i8(i32x4 a, i32x4 b, i32x4 c) { return __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, 0, 0, 0); }
@@ -253,76 +256,113 @@ DEV void digits4(int p01, int p23, int &hi, int &lo) {
     lo = __builtin_amdgcn_perm(p23, p01, 0x06040200u) ^ 0x80808080;     // (a & 255) - 128 as a signed byte
 }
 
-__global__ __launch_bounds__(MW * 64, 2) void k_q88_mfma(const int *__restrict__ iq, int64_t S, int64_t L, int64_t cpr,
-                                                         int64_t n_chunks, Q88Weights wt, const short *__restrict__ lut,
-                                                         int *__restrict__ out) {
-    __shared__ __attribute__((aligned(16))) unsigned char planes[MW][WAVE_LDS];
-    __shared__ int s_lut[256];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, kb = lane >> 4;
-    s_lut[tid] = lut[tid];
-    unsigned char *pl = planes[wave];
-    for (int k = lane; k < WAVE_LDS / 4; k += 64) reinterpret_cast<int *>(pl)[k] = 0;
-    __syncthreads();
+// exact floor(sqrt(s)) for s <= 2^31 in 32-bit arithmetic: the float estimate is off by at most one
+DEV unsigned isqrt31(unsigned s) {
+    unsigned t = (unsigned)sqrtf((float)s);
+    t -= (t * t > s) ? 1u : 0u;
+    t += ((t + 1u) * (t + 1u) <= s) ? 1u : 0u;
+    return t;
+}
+DEV int envelope_q88_fast(unsigned s) {      // envelope_q88 with isqrt31 (s = i^2 + q^2 <= 2^31)
+    const unsigned t = isqrt31(s);
+    const int q = (int)(t >> 7), rem = (int)(t & 127);
+    const bool exact = t * t == s;
+    const bool up = rem > 64 || (rem == 64 && (!exact || (q & 1)));
+    return q + (up ? 1 : 0);
+}
 
-    // ---- weight images and start values (once per wave)
+// Weight images and accumulator start values of the matrix-core form, per lane: IMG_N quads in the order
+// A1[t][v] (6), A2[v] (3), A3 high / low digits (2), c1[t] (2), c2, c3.  Built once per set of weights
+// (dpd_q88_matrix_prepare), stored [quad][lane], read by every wave with 15 coalesced 16-byte loads.
+constexpr int IMG_N = 15;
+__global__ __launch_bounds__(64) void k_q88_prepare(Q88Weights wt, i32x4 *__restrict__ image) {
+    const int lane = threadIdx.x, j = lane & 15, kb = lane >> 4, quad = blockIdx.x;
     const bool act_hi_lane = kb < 2;          // FC1: lane groups 0, 1 meet high activation digits
     const int half = kb & 1;
-    i32x4 A1[2][3], A2[3], A3[3];
+    int by[16];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+    for (int e = 0; e < 16; ++e) by[e] = 0;
+    i32x4 res;
+    if (quad < 6) {                           // FC1 row tile t, variant v
+        const int t = quad / 3, v = quad % 3;
 #pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            int by[16];
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                int series, tap;
-                fc1_slot(half, e, series, tap);
-                const int w = series >= 0 ? wt.w1[(16 * t + j) * 30 + feature_index(series, tap)] : 0;
-                by[e] = image_byte(w, act_hi_lane, v);
-            }
-            A1[t][v] = i32x4{pack4(by[0], by[1], by[2], by[3]), pack4(by[4], by[5], by[6], by[7]),
-                             pack4(by[8], by[9], by[10], by[11]), pack4(by[12], by[13], by[14], by[15])};
+        for (int e = 0; e < 16; ++e) {
+            int series, tap;
+            fc1_slot(half, e, series, tap);
+            const int w = series >= 0 ? wt.w1[(16 * t + j) * 30 + feature_index(series, tap)] : 0;
+            by[e] = image_byte(w, act_hi_lane, v);
         }
-#pragma unroll
-    for (int v = 0; v < 3; ++v) {
-        int by[16], bz[16];
+    } else if (quad < 9) {                    // FC2, variant v
+        const int v = quad - 6;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int ee = e & 7;
             const int m2 = ee < 4 ? 4 * kb + ee : 16 + 4 * kb + (ee - 4);     // FC2 input neuron of this byte
             by[e] = image_byte(wt.w2[j * 32 + m2], e < 8, v);
-            const int m3 = 4 * kb + (e & 3);                                   // FC3: bytes 0..3 high, 4..7 low, 8..15 unused
-            bz[e] = (e < 8 && j < 2) ? image_byte(wt.w3[j * 16 + m3], e < 4, v) : 0;
         }
-        A2[v] = i32x4{pack4(by[0], by[1], by[2], by[3]), pack4(by[4], by[5], by[6], by[7]),
-                      pack4(by[8], by[9], by[10], by[11]), pack4(by[12], by[13], by[14], by[15])};
-        A3[v] = i32x4{pack4(bz[0], bz[1], bz[2], bz[3]), pack4(bz[4], bz[5], bz[6], bz[7]), 0, 0};
-    }
-    // start of the LL accumulators: (bias << 15) + 128 sum_k w[n][k] for the neurons 4 kb + r of each row tile
-    i32x4 c1[2], c2, c3;
+    } else if (quad < 11) {
+        // FC3 for the four tiles of a chunk at once: result row 4 c + o = output o of tile c, K slot (kb, c, r) = neuron
+        // 4 kb + r of tile c (what lane (kb, j) holds of tile c after FC2).  Lane (i, kb) of the weight image: row
+        // i = 4 c' + o, byte 4 c + r: digit of W3[o][4 kb + r] where c == c', else 0.  High digits (quad 9), low (10).
+        const int cq = j >> 2, o = j & 3;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            const int n = 16 * t + 4 * kb + r;
-            int sw = 0;
-            for (int k = 0; k < 30; ++k) sw += wt.w1[n * 30 + k];
-            c1[t][r] = ((int)wt.b1[n] << 15) + 128 * sw;
-        }
-        {
-            const int n = 4 * kb + r;
-            int sw = 0;
-            for (int k = 0; k < 32; ++k) sw += wt.w2[n * 32 + k];
-            c2[r] = ((int)wt.b2[n] << 15) + 128 * sw;
-        }
-        {
-            const int n = 4 * kb + r;
-            int sw = 0;
-            if (n < 2)
-                for (int k = 0; k < 16; ++k) sw += wt.w3[n * 16 + k];
-            c3[r] = n < 2 ? ((int)wt.b3[n] << 15) + 128 * sw : 0;
+        for (int e = 0; e < 16; ++e) {
+            const int c = e >> 2, r = e & 3;
+            const int w = (c == cq && o < 2) ? wt.w3[o * 16 + 4 * kb + r] : 0;
+            by[e] = quad == 9 ? digit_hi(w) : digit_lo(w);
         }
     }
+    if (quad < 11) {
+        res = i32x4{pack4(by[0], by[1], by[2], by[3]), pack4(by[4], by[5], by[6], by[7]),
+                    pack4(by[8], by[9], by[10], by[11]), pack4(by[12], by[13], by[14], by[15])};
+    } else {
+        // start of the LL accumulators: (bias << 15) + 128 sum_k w[n][k] for the rows 4 kb + r of a result tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            int sw = 0, bias = 0;
+            if (quad < 13) {                  // FC1 row tile t
+                const int n = 16 * (quad - 11) + 4 * kb + r;
+                for (int k = 0; k < 30; ++k) sw += wt.w1[n * 30 + k];
+                bias = wt.b1[n];
+            } else if (quad == 13) {
+                const int n = 4 * kb + r;
+                for (int k = 0; k < 32; ++k) sw += wt.w2[n * 32 + k];
+                bias = wt.b2[n];
+            } else if (r < 2) {               // FC3 result rows 4 c + r: output r of every tile
+                for (int k = 0; k < 16; ++k) sw += wt.w3[r * 16 + k];
+                bias = wt.b3[r];
+            }
+            res[r] = (bias << 15) + 128 * sw;
+        }
+    }
+    image[quad * 64 + lane] = res;
+}
+
+__global__ __launch_bounds__(MW * 64, Q88_MFMA_WAVES) void k_q88_mfma(const int *__restrict__ iq, int64_t S, int64_t L, unsigned cpr,
+                                                         unsigned n_chunks, unsigned unit, const i32x4 *__restrict__ image,
+                                                         const short *__restrict__ lut, int *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char planes[MW][WAVE_LDS];
+    __shared__ int s_lut[256];
+    const int tid = threadIdx.x, lane = tid & 63, j = lane & 15, kb = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    s_lut[tid] = lut[tid];
+    unsigned char *pl = planes[wave];
+    for (int k = lane; k < WAVE_LDS / 4; k += 64) reinterpret_cast<int *>(pl)[k] = 0;
+    __syncthreads();
+    const int half = kb & 1;
+    i32x4 A1[2][3], A2[3], A3h, A3l, c1[2], c2, c3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int v = 0; v < 3; ++v) A1[t][v] = image[(3 * t + v) * 64 + lane];
+#pragma unroll
+    for (int v = 0; v < 3; ++v) A2[v] = image[(6 + v) * 64 + lane];
+    A3h = image[9 * 64 + lane];
+    A3l = image[10 * 64 + lane];
+    c1[0] = image[11 * 64 + lane];
+    c1[1] = image[12 * 64 + lane];
+    c2 = image[13 * 64 + lane];
+    c3 = image[14 * 64 + lane];
     // FC1 operand gather: three runs of consecutive bytes, the same instruction sequence in every lane
     const int digit = kb >> 1;
     const int pA = (digit * 5 + (half ? 3 : 0)) * PLANE + j;
@@ -332,31 +372,65 @@ __global__ __launch_bounds__(MW * 64, 2) void k_q88_mfma(const int *__restrict__
     const unsigned char *qA = pl + (pA & ~3), *qB = pl + (pB & ~3), *qC = pl + (pC & ~3);
     const i32x4 zero4 = {0, 0, 0, 0};
 
-    const int64_t n_waves = (int64_t)gridDim.x * MW;
-    for (int64_t chunk = (int64_t)blockIdx.x * MW + wave; chunk < n_chunks; chunk += n_waves) {
-        const int64_t row = chunk / cpr, t0 = (chunk - row * cpr) * 64;
-        const int *p = iq + row * S + t0;          // p[u]: point u of the chunk; output t uses points t .. t + 5
-        __builtin_amdgcn_wave_barrier();
+    // one time point of the chunk: its five Q8.8 features as digits into the byte planes
+    auto commit = [&](int v, int u) {
+        const int i = (short)(v & 0xffff), q = v >> 16;
+        const unsigned ss = (unsigned)(i * i) + (unsigned)(q * q);
+        int f[5];
+        f[0] = sat16(rhe_shift(i, 7));
+        f[1] = sat16(rhe_shift(q, 7));
+        f[2] = envelope_q88_fast(ss);
+        f[3] = (int)((ss + ((1u << 21) - 1) + ((ss >> 22) & 1u)) >> 22);       // ss <= 2^31: the sum fits 32 bits
+        f[4] = (int)(((unsigned long long)ss * ss + (1ull << 51)) >> 52);
 #pragma unroll
-        for (int rep = 0; rep < 2; ++rep) {
-            const int u = lane + 64 * rep;
-            if (rep == 1 && lane >= 5) break;
-            const int v = (t0 + u < S) ? p[u] : 0;
-            const int i = (short)(v & 0xffff), q = v >> 16;
-            const unsigned ss = (unsigned)(i * i) + (unsigned)(q * q);
-            int f[5];
-            f[0] = sat16(rhe_shift(i, 7));
-            f[1] = sat16(rhe_shift(q, 7));
-            f[2] = envelope_q88(ss);
-            f[3] = (int)(((unsigned long long)ss + ((1u << 21) - 1) + ((ss >> 22) & 1u)) >> 22);
-            f[4] = (int)(((unsigned long long)ss * ss + (1ull << 51)) >> 52);
-#pragma unroll
-            for (int s5 = 0; s5 < 5; ++s5) {
-                pl[s5 * PLANE + u] = (unsigned char)(f[s5] >> 8);
-                pl[(5 + s5) * PLANE + u] = (unsigned char)((f[s5] & 0xff) ^ 0x80);
-            }
+        for (int s5 = 0; s5 < 5; ++s5) {
+            pl[s5 * PLANE + u] = (unsigned char)(f[s5] >> 8);
+            pl[(5 + s5) * PLANE + u] = (unsigned char)((f[s5] & 0xff) ^ 0x80);
         }
+    };
+
+    // A wave walks runs of `unit` consecutive chunks (runs dealt round robin over the waves; scalar arithmetic).  Inside a
+    // run of one row the five history points of a chunk are the last five of its predecessor: their digits are moved
+    // inside LDS; only the first chunk of a run (or of a row) derives them.  The next chunk's points are loaded one
+    // chunk ahead.
+    const unsigned n_waves = gridDim.x * MW;
+    unsigned chunk = (blockIdx.x * MW + wave) * unit, k_in_unit = 0;
+    unsigned row = chunk / cpr, pos = chunk - row * cpr;
+    bool fresh = true;
+    int pre = 0, pre_h = 0;
+    auto fetch = [&](unsigned r, unsigned ps, bool fr) {
+        const int *p = iq + (int64_t)r * S + (int64_t)ps * 64;
+        const int64_t tb = (int64_t)ps * 64;
+        pre = (tb + 5 + lane < S) ? p[5 + lane] : 0;
+        if (fr) pre_h = (lane < 5 && tb + lane < S) ? p[lane] : 0;
+    };
+    if (chunk < n_chunks) fetch(row, pos, true);
+    while (chunk < n_chunks) {
+        if (fresh) {
+            if (lane < 5) commit(pre_h, lane);
+        } else if (lane < 50) {
+            const int plane = lane / 5, off = lane - 5 * plane;
+            pl[plane * PLANE + off] = pl[plane * PLANE + 64 + off];
+        }
+        commit(pre, 5 + lane);
+        const int64_t t0 = (int64_t)pos * 64, row_cur = row;
+        if (++k_in_unit < unit) {
+            chunk += 1;
+            fresh = ++pos == cpr;
+            if (fresh) {
+                pos = 0;
+                ++row;
+            }
+        } else {
+            k_in_unit = 0;
+            chunk += 1 + (n_waves - 1) * unit;
+            row = chunk / cpr;
+            pos = chunk - row * cpr;
+            fresh = true;
+        }
+        if (chunk < n_chunks) fetch(row, pos, fresh);
         __builtin_amdgcn_wave_barrier();
+        int x3h[4] = {0, 0, 0, 0}, x3l[4] = {0, 0, 0, 0};     // FC2 results of the four tiles, as digits
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
             if (t0 + 16 * c >= L) break;           // wave-uniform
@@ -380,16 +454,21 @@ __global__ __launch_bounds__(MW * 64, 2) void k_q88_mfma(const int *__restrict__
             digits4(p1[2], p1[3], h1, l1);           // bytes 4..7 / 12..15: row tile 1
             const i32x4 X2 = {h0, h1, l0, l1};
             // ---- FC2
-            int p2[2];
+            int p20, p21;
             {
                 const i32x4 hh = mfma_i8(A2[0], X2, zero4), xx = mfma_i8(A2[1], X2, zero4), ll = mfma_i8(A2[2], X2, c2);
-                requant_act4(hh, xx, ll, p2[0], p2[1]);
+                requant_act4(hh, xx, ll, p20, p21);
             }
-            int h2, l2;
-            digits4(p2[0], p2[1], h2, l2);
-            const i32x4 X3 = {h2, l2, 0, 0};
-            // ---- FC3 and the output table: rows 0, 1 of the result = registers 0, 1 of lane group 0
-            const i32x4 hh = mfma_i8(A3[0], X3, zero4), xx = mfma_i8(A3[1], X3, zero4), ll = mfma_i8(A3[2], X3, c3);
+            digits4(p20, p21, x3h[c], x3l[c]);
+            __builtin_amdgcn_sched_barrier(0);     // one tile at a time: keeps the register count down
+        }
+        // ---- FC3 of the whole chunk and the output table: lane (c, j) gets outputs 0, 1 of sample 16 c + j = its own lane index
+        {
+            const i32x4 Xh = {x3h[0], x3h[1], x3h[2], x3h[3]}, Xl = {x3l[0], x3l[1], x3l[2], x3l[3]};
+            const i32x4 hh = mfma_i8(A3h, Xh, zero4);
+            i32x4 xx = mfma_i8(A3l, Xh, zero4);
+            xx = mfma_i8(A3h, Xl, xx);
+            const i32x4 ll = mfma_i8(A3l, Xl, c3);
             int o[2];
 #pragma unroll
             for (int r = 0; r < 2; ++r) {
@@ -399,8 +478,8 @@ __global__ __launch_bounds__(MW * 64, 2) void k_q88_mfma(const int *__restrict__
                 idx = min(max(idx, 0), 255);
                 o[r] = s_lut[idx];
             }
-            const int64_t t = t0 + 16 * c + j;
-            if (kb == 0 && t < L) out[row * L + t] = pack2(o[0], o[1]);
+            const int64_t t = t0 + lane;
+            if (t < L) out[row_cur * L + t] = pack2(o[0], o[1]);
         }
     }
 }
@@ -412,7 +491,6 @@ extern "C" int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int1
                              const int16_t *lut, int acc64, int16_t *out, void *stream) {
     DPD_REQUIRE(((iq && out) || B == 0) && w1 && b1 && w2 && b2 && w3 && b3 && lut, DPD_ERR_INVALID_ARG, "q88_infer: null pointer");
     DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
-    DPD_REQUIRE(acc64 >= 0 && acc64 <= 2, DPD_ERR_INVALID_ARG, "q88_infer: mode %d not in 0..2", acc64);
     auto aligned4 = [](const void *q) { return (reinterpret_cast<uintptr_t>(q) & 3) == 0; };
     DPD_REQUIRE(aligned4(iq) && aligned4(out) && aligned4(w1) && aligned4(b1) && aligned4(w2) && aligned4(b2) &&
                     aligned4(w3) && aligned4(b3),
@@ -424,18 +502,47 @@ extern "C" int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int1
     const int *iqp = reinterpret_cast<const int *>(iq);
     int *op = reinterpret_cast<int *>(out);
     auto dw = [](const int16_t *q) { return reinterpret_cast<const int *>(q); };
-    if (acc64 == 2) {
-        const int64_t cpr = (L + 63) / 64, n_chunks = B * cpr;
-        int64_t blocks = (n_chunks + MW - 1) / MW;
-        if (blocks > 256 * 4) blocks = 256 * 4;
-        const Q88Weights wt{w1, b1, w2, b2, w3, b3};
-        hipLaunchKernelGGL(k_q88_mfma, dim3((unsigned)blocks), dim3(MW * 64), 0, st, iqp, S, L, cpr, n_chunks, wt, lut, op);
-    } else if (acc64)
+    if (acc64)
         hipLaunchKernelGGL((k_q88<true>), grid, block, 0, st, iqp, S, L, segs_per_row, n_segs, dw(w1), dw(b1), dw(w2),
                            dw(b2), dw(w3), dw(b3), lut, op);
     else
         hipLaunchKernelGGL((k_q88<false>), grid, block, 0, st, iqp, S, L, segs_per_row, n_segs, dw(w1), dw(b1), dw(w2),
                            dw(b2), dw(w3), dw(b3), lut, op);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+// ---- matrix-core form: prepared weight image + inference ------------------------------------------------
+extern "C" size_t dpd_q88_matrix_image_bytes(void) { return (size_t)IMG_N * 64 * sizeof(i32x4); }
+
+extern "C" int dpd_q88_matrix_prepare(const int16_t *w1, const int16_t *b1, const int16_t *w2, const int16_t *b2,
+                                      const int16_t *w3, const int16_t *b3, void *image, void *stream) {
+    DPD_REQUIRE(w1 && b1 && w2 && b2 && w3 && b3 && image, DPD_ERR_INVALID_ARG, "q88_matrix_prepare: null pointer");
+    DPD_REQUIRE((reinterpret_cast<uintptr_t>(image) & 15) == 0, DPD_ERR_INVALID_ARG, "q88_matrix_prepare: image must be 16-byte aligned");
+    const Q88Weights wt{w1, b1, w2, b2, w3, b3};
+    hipLaunchKernelGGL(k_q88_prepare, dim3(IMG_N), dim3(64), 0, as_stream(stream), wt, reinterpret_cast<i32x4 *>(image));
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+extern "C" int dpd_q88_matrix_infer(const int16_t *iq, int64_t B, int64_t S, const void *image, const int16_t *lut,
+                                    int16_t *out, void *stream) {
+    DPD_REQUIRE(((iq && out) || B == 0) && image && lut, DPD_ERR_INVALID_ARG, "q88_matrix_infer: null pointer");
+    DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
+    DPD_REQUIRE((reinterpret_cast<uintptr_t>(iq) & 3) == 0 && (reinterpret_cast<uintptr_t>(out) & 3) == 0 &&
+                    (reinterpret_cast<uintptr_t>(image) & 15) == 0,
+                DPD_ERR_INVALID_ARG, "q88_matrix_infer: iq and out must be 4-byte aligned, the image 16-byte aligned");
+    if (B <= 0) return DPD_OK;
+    const int64_t L = S - DPD_GEN_MEMORY, cpr = (L + 63) / 64, n_chunks = B * cpr;
+    DPD_REQUIRE(n_chunks < ((int64_t)1 << 31) - 65536, DPD_ERR_SHAPE, "q88_matrix_infer: %lld chunks exceed the 32-bit chunk counter", (long long)n_chunks);
+    int64_t blocks = (n_chunks + MW - 1) / MW;
+    if (blocks > 256 * Q88_MFMA_WAVES) blocks = 256 * Q88_MFMA_WAVES;
+    // consecutive chunks per run: as many as keep every wave busy, at most a row's worth of 16
+    int64_t unit = n_chunks / (blocks * MW);
+    unit = unit < 1 ? 1 : unit > 16 ? 16 : unit;
+    hipLaunchKernelGGL(k_q88_mfma, dim3((unsigned)blocks), dim3(MW * 64), 0, as_stream(stream), reinterpret_cast<const int *>(iq), S, L,
+                       (unsigned)cpr, (unsigned)n_chunks, (unsigned)unit, reinterpret_cast<const i32x4 *>(image), lut,
+                       reinterpret_cast<int *>(out));
     DPD_LAUNCH_CHECK();
     return DPD_OK;
 }

@@ -274,6 +274,13 @@ class Q88Inference:
         fit = L.lib().dpd_q88_digits_fit(*(L.c_p(host[i].data_ptr()) for i in (0, 2, 4)))
         self.acc64 = bool(force_acc64 or not safe)
         self.mode = self.MODE_VALU64 if self.acc64 else (self.MODE_MATRIX if (fit and not force_valu) else self.MODE_VALU32)
+        self.image = None      # weight image of the matrix-core kernel, built at the first call
+
+    def _prepare_image(self):
+        i16 = torch.int16
+        self.image = torch.empty(int(L.lib().dpd_q88_matrix_image_bytes()), dtype=torch.uint8, device=self.w["w1"].device)
+        L.call("dpd_q88_matrix_prepare", *(L.fptr(self.w[k], i16) for k in ("w1", "b1", "w2", "b2", "w3", "b3")),
+               L.c_p(self.image.data_ptr()), L.stream())
 
     def __call__(self, iq: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """`out` (optional, int16 [B, S-5, 2], contiguous) receives the result in place of a new tensor: a
@@ -290,6 +297,12 @@ class Q88Inference:
         elif tuple(out.shape) != (B, S - 5, 2) or out.dtype != torch.int16 or not out.is_contiguous():
             raise RuntimeError(f"out must be a contiguous int16 tensor of shape {(B, S - 5, 2)}")
         i16 = torch.int16
+        if self.mode == self.MODE_MATRIX:
+            if self.image is None:
+                self._prepare_image()
+            L.call("dpd_q88_matrix_infer", L.fptr(x, i16), B, S, L.c_p(self.image.data_ptr()), L.fptr(self.w["lut"], i16),
+                   L.fptr(out, i16), L.stream())
+            return out
         L.call("dpd_q88_infer", L.fptr(x, i16), B, S, *(L.fptr(self.w[k], i16) for k in ("w1", "b1", "w2", "b2", "w3", "b3")),
-               L.fptr(self.w["lut"], i16), int(self.mode), L.fptr(out, i16), L.stream())
+               L.fptr(self.w["lut"], i16), int(self.acc64), L.fptr(out, i16), L.stream())
         return out

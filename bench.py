@@ -158,7 +158,7 @@ class KernelTimer:
         self.orig = _lib.call
 
         def call(n, *a):
-            if n != self.name or not self.on or (self.when is not None and not self.when(a)):
+            if (n not in self.name if isinstance(self.name, tuple) else n != self.name) or not self.on or (self.when is not None and not self.when(a)):
                 return self.orig(n, *a)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -228,7 +228,7 @@ def run_stage1(ctx, args, qat, steps, warmup):
     roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma: tap assembly + forward + MSE + backward, fp32 MFMA (+ slab reduce)",
             "achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS,
-            "traffic": pmc_bytes("k_gen_bwd_mfma<%s,true>" % ("true" if qat else "false")) if default_shape(ctx) else None,
+            "traffic": pmc_bytes("k_gen_bwd_mfma<%s,true,false>" % ("true" if qat else "false")) if default_shape(ctx) else None,
             "flop_per_sample": 2 * (GEN_FWD_MAC + GEN_BWD_MAC), "kernel_ms": k * 1e3}
     if qat:
         # the four abs-max passes recompute the forward up to the layer whose scale they produce: work that the
@@ -298,11 +298,24 @@ def q88_engine(ctx):
 def q88_roof(ctx, k, eng):
     n = ctx.rows * (ctx.seq - 5)
     mac = GEN_FWD_MAC * n
-    # v_dot2c_i32_i16 issues at 16 lanes per SIMD-cycle (half the fp32 FMA rate; scratch/ubench/dot2_rate.hip
+    # integer-VALU ceiling: v_dot2c_i32_i16 issues at 16 lanes per SIMD-cycle (half the fp32 FMA rate; scratch/ubench/dot2_rate.hip
     # measures 36.4 T lane-instructions/s): 256 CU x 4 SIMD x 16 lanes x 2 MAC x 2.4 GHz = 78.6 TMAC/s
-    return {"bound": "valu-int", "kernel": "k_q88 (v_dot2c_i32_i16)", "achieved": mac / k / 1e12, "peak": 78.6,
-            "unit": "TMAC/s", "frac": mac / k / 1e12 / 78.6, "traffic": pmc_bytes("k_q88") if default_shape(ctx) else None,
-            "hbm_gbs": 8.0 * n / k / 1e9, "acc64": eng.acc64, "kernel_ms": k * 1e3}
+    roof = {"bound": "valu-int", "achieved": mac / k / 1e12, "peak": 78.6, "unit": "TMAC/s", "frac": mac / k / 1e12 / 78.6,
+            "traffic": None, "hbm_gbs": 8.0 * n / k / 1e9, "kernel_ms": k * 1e3, "mac_per_sample": GEN_FWD_MAC}
+    if getattr(eng, "mode", 0) == 2:
+        # matrix-core form: every int16 MAC is four int8 MACs (two digits per operand); the kernel executes 10,240 int8 MACs per
+        # sample (6 + 3 MFMAs of 16x16x64 per 16 samples and 4 per 64 samples, K partly padding) against 6,016 useful ones.  Dense
+        # int8 MFMA peak: twice the bf16 rate = 2.5e15 MAC/s
+        roof.update(kernel="k_q88_mfma (v_mfma_i32_16x16x64_i8, int16 = two 8-bit digits, three int32 accumulators per product)",
+                    frac_definition="int16 MACs per second against the integer-VALU ceiling of v_dot2c_i32_i16 (the roofline of the "
+                                    "VALU form of this path); above 1 means the matrix cores carry the MACs faster than the VALU could",
+                    mfma_i8_frac=10240.0 * n / k / 2.5e15, mfma_i8_useful_frac=4.0 * mac / k / 2.5e15,
+                    traffic=pmc_bytes("k_q88_mfma") if default_shape(ctx) else None,
+                    note="bound by the requantisation around the products (about 10 integer VALU instructions per neuron and sample), "
+                         "not by the matrix pipe or HBM")
+    else:
+        roof.update(kernel="k_q88 (v_dot2c_i32_i16)", acc64=eng.acc64, traffic=pmc_bytes("k_q88<false>") if default_shape(ctx) else None)
+    return roof
 
 
 def run_q88(ctx, args, steps, warmup):
@@ -314,7 +327,7 @@ def run_q88(ctx, args, steps, warmup):
     def fn():
         for x in iq16:
             out[0] = eng(x)
-    kt = KernelTimer("dpd_q88_infer")
+    kt = KernelTimer(("dpd_q88_infer", "dpd_q88_matrix_infer"))
     for _ in range(warmup):
         fn()
     kt.on = True
@@ -344,7 +357,7 @@ def run_q88_stream(ctx, args, steps, warmup):
         v = outs.view(torch.int32).to(torch.int64)
         idx = torch.arange(v.numel(), device=ctx.dev, dtype=torch.int64).view_as(v)
         return int(((v * ((idx % 65521) + 1)).sum() % 2305843009213693951).item())
-    kt = KernelTimer("dpd_q88_infer")
+    kt = KernelTimer(("dpd_q88_infer", "dpd_q88_matrix_infer"))
     for _ in range(warmup):
         fn()
     first = checksum()
@@ -383,11 +396,11 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
     kflop = (2.0 * GEN_FWD_MAC + (0 if qat else PA_FLOP)) * n
     flop = (2.0 * GEN_FWD_MAC + PA_FLOP) * n
     t = dt / steps / ctx.micro
-    kname = ("k_gen_fwd_mfma<true,3,false>: tap assembly + QAT generator forward to the unquantised output (4th abs-max pass)" if qat else
-             "k_gen_fwd_mfma<false,4,true>: tap assembly + generator + PA twin in one kernel")
+    kname = ("k_gen_fwd_mfma<true,3,0>: tap assembly + QAT generator forward to the unquantised output (4th abs-max pass)" if qat else
+             "k_gen_fwd_mfma<false,4,3>: tap assembly + generator + PA twin in one kernel (whole rows per wave, outputs carried)")
     roof = {"bound": "mfma", "kernel": kname,
             "achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kflop / k / 1e12 / FP32_PEAK_TFLOPS,
-            "traffic": pmc_bytes("k_gen_fwd_mfma<true,3,false>" if qat else "k_gen_fwd_mfma<false,4,true>") if default_shape(ctx) else None,
+            "traffic": pmc_bytes("k_gen_fwd_mfma<true,3,0>" if qat else "k_gen_fwd_mfma<false,4,3>") if default_shape(ctx) else None,
             "flop_per_sample": 2 * GEN_FWD_MAC + (0 if qat else PA_FLOP), "kernel_ms": k * 1e3,
             "chain_frac": flop / t / 1e12 / FP32_PEAK_TFLOPS}
     if qat:
@@ -420,7 +433,7 @@ def run_gen_pa_train(ctx, args, steps, warmup):
     flop = (2.0 * (GEN_FWD_MAC + GEN_BWD_MAC) + PA_FLOP + PA_BWD_FLOP) * n
     roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma<QAT,PA>: tap assembly + generator + quantiser + PA twin + MSE + PA adjoint + generator backward",
             "achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS,
-            "traffic": pmc_bytes("k_gen_bwd_mfma<true,pa>") if default_shape(ctx) else None,
+            "traffic": pmc_bytes("k_gen_bwd_mfma<true,true,true>") if default_shape(ctx) else None,
             "flop_per_sample": 2 * (GEN_FWD_MAC + GEN_BWD_MAC) + PA_FLOP + PA_BWD_FLOP, "kernel_ms": k * 1e3}
     return dt, roof, {"loss": float(step.grads[1554].item())}
 

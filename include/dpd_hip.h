@@ -279,11 +279,9 @@ int dpd_fake_quantize_dynamic(const float *x, int64_t rows, int64_t cols, int pe
 /* Bit-exact Q8.8 inference: iq int16 Q1.15 [B,S,2] -> out int16 Q1.15 [B,S-5,2].
  * Weights int16 Q1.15 (w1 [32,30], w2 [16,32], w3 [2,16]), biases int16 Q8.8, accumulators Q9.23,
  * requantisation round-half-even with saturation (utils/quantization.py:88-120, :213-256),
- * tanh through the 256-entry table of generate_tanh_lut (:365-393).  acc64 selects the kernel, all three
- * give the same bits: 1 = integer VALU with 64-bit accumulators (any weights); 0 = integer VALU with 32-bit
- * accumulators (v_dot2_i32_i16), requires dpd_q88_int32_safe() to hold for the weights; 2 = the int8 matrix cores
- * (every int16 as two 8-bit digits, three int32 accumulators per product), requires dpd_q88_int32_safe() and
- * dpd_q88_digits_fit(). */
+ * tanh through the 256-entry table of generate_tanh_lut (:365-393).  Integer VALU kernels: acc64 != 0 forces
+ * 64-bit accumulators; acc64 == 0 (v_dot2_i32_i16, 32-bit accumulators) requires dpd_q88_int32_safe() to hold
+ * for the weights. */
 int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int16_t *w1, const int16_t *b1,
                   const int16_t *w2, const int16_t *b2, const int16_t *w3, const int16_t *b3,
                   const int16_t *lut, int acc64, int16_t *out, void *stream);
@@ -293,9 +291,19 @@ int dpd_q88_infer(const int16_t *iq, int64_t B, int64_t S, const int16_t *w1, co
 int dpd_q88_int32_safe(const int16_t *h_w1, const int16_t *h_b1, const int16_t *h_w2, const int16_t *h_b2,
                        const int16_t *h_w3, const int16_t *h_b3);
 
-/* Host-side check for mode 2 of dpd_q88_infer: 1 if every weight is <= 32639 (splits into two signed 8-bit
- * digits), 0 otherwise. */
+/* The same inference on the int8 matrix cores (v_mfma_i32_16x16x64_i8): every int16 as two 8-bit digits, three
+ * int32 accumulators per product, bit-identical to dpd_q88_infer.  Allowed when dpd_q88_int32_safe() holds and every
+ * weight is <= 32639 (dpd_q88_digits_fit(), host pointers: a larger weight has no signed 8-bit high digit).
+ * dpd_q88_matrix_prepare builds the weight image (dpd_q88_matrix_image_bytes() bytes of device memory, 16-byte
+ * aligned, caller-owned) from the device weights once per set of weights; dpd_q88_matrix_infer then serves any number
+ * of batches from it.  Same reference contract as dpd_q88_infer (it stands for the same composition of
+ * utils/quantization.py:88-120, :213-256, :365-393). */
 int dpd_q88_digits_fit(const int16_t *h_w1, const int16_t *h_w2, const int16_t *h_w3);
+size_t dpd_q88_matrix_image_bytes(void);
+int dpd_q88_matrix_prepare(const int16_t *w1, const int16_t *b1, const int16_t *w2, const int16_t *b2,
+                           const int16_t *w3, const int16_t *b3, void *image, void *stream);
+int dpd_q88_matrix_infer(const int16_t *iq, int64_t B, int64_t S, const void *image, const int16_t *lut,
+                         int16_t *out, void *stream);
 
 #ifdef __cplusplus
 }

@@ -23,7 +23,8 @@ def test_header_declares_the_expected_surface():
     for name in ("dpd_gen_forward", "dpd_gen_backward", "dpd_gen_mse_step", "dpd_gen_absmax_pass", "dpd_tap_assembly",
                  "dpd_pa_forward", "dpd_pa_backward", "dpd_quant_pa_forward", "dpd_gen_pa_forward", "dpd_critic_sn_forward", "dpd_critic_sn_backward", "dpd_critic_forward", "dpd_critic_backward",
                  "dpd_critic_gp", "dpd_spectral_stats", "dpd_spectral_backward", "dpd_spectral_rowdb", "dpd_spectral_loss_final", "dpd_spectral_terms_backward", "dpd_quantize_fixed",
-                 "dpd_fake_quantize_dynamic", "dpd_q88_infer", "dpd_q88_int32_safe", "dpd_workspace_bytes"):
+                 "dpd_fake_quantize_dynamic", "dpd_q88_infer", "dpd_q88_int32_safe", "dpd_q88_digits_fit", "dpd_q88_matrix_image_bytes",
+                 "dpd_q88_matrix_prepare", "dpd_q88_matrix_infer", "dpd_workspace_bytes"):
         assert name in syms
 
 
@@ -68,9 +69,14 @@ def test_argument_errors_without_gpu():
     q = ctypes.cast(i16, ctypes.c_void_p)
     lib.dpd_q88_int32_safe.argtypes = [ctypes.c_void_p] * 6
     assert lib.dpd_q88_int32_safe(q, q, q, q, q, q) == 1          # all-zero weights cannot overflow
+    lib.dpd_q88_digits_fit.argtypes = [ctypes.c_void_p] * 3
+    assert lib.dpd_q88_digits_fit(q, q, q) == 1
+    lib.dpd_q88_matrix_image_bytes.restype = ctypes.c_size_t
+    assert lib.dpd_q88_matrix_image_bytes() == 15 * 64 * 16
     for i in range(1024):
         i16[i] = 32767
     assert lib.dpd_q88_int32_safe(q, q, q, q, q, q) == 0
+    assert lib.dpd_q88_digits_fit(q, q, q) == 0                   # 32767 has no signed 8-bit high digit
 
 
 def test_host_layer_has_no_cpu_path():

@@ -161,13 +161,16 @@ def test_fixed_point_primitives_bit_exact():
             load_weights_binary(os.path.join(d, "bad.bin"))
 
 
-@pytest.mark.parametrize("acc64", [False, True])
-def test_q88_golden_bit_exact(acc64):
+@pytest.mark.parametrize("kernel", ["matrix", "valu32", "valu64"])
+def test_q88_golden_bit_exact(kernel):
+    """The three kernels of the integer path (int8 matrix cores, integer VALU with 32-bit and with 64-bit
+    accumulators) against the fixture, bit for bit."""
     from dpd_amd.utils import Q88Inference
     g = load_golden("g11_q88")
     w = {k: T(g[k]) for k in ("w1", "b1", "w2", "b2", "w3", "b3", "lut")}
-    eng = Q88Inference(w, force_acc64=acc64)
-    assert eng.acc64 == acc64          # these weights are provably safe for 32-bit accumulation
+    eng = Q88Inference(w, force_acc64=kernel == "valu64", force_valu=kernel == "valu32")
+    # these weights are provably safe for 32-bit accumulation and split into 8-bit digits: the default is the matrix form
+    assert eng.mode == {"matrix": 2, "valu32": 0, "valu64": 1}[kernel] and eng.acc64 == (kernel == "valu64")
     out = eng(T(g["iq_i16"]))
     assert np.array_equal(out.cpu().numpy()[0], g["out_i16"])
     with pytest.raises(ValueError):
@@ -199,8 +202,35 @@ def test_q88_random_rows_and_extremes_vs_oracle():
         out = eng(T(iq)).cpu().numpy()
         ref = oq.infer_rows(iq, *ws, g["lut"])
         assert np.array_equal(out, ref)
-        if not expect64:      # the 64-bit kernel on the same weights
+        if not expect64:      # the other two kernels on the same weights
+            assert eng.mode == 2
             assert np.array_equal(Q88Inference(w, force_acc64=True)(T(iq)).cpu().numpy(), ref)
+            assert np.array_equal(Q88Inference(w, force_valu=True)(T(iq)).cpu().numpy(), ref)
+    # a weight above 32639 has no signed 8-bit high digit: the matrix form is not selected
+    top = [a.copy() for a in base]
+    top[0][3, 7] = 32767
+    w = {k: T(a) for k, a in zip(("w1", "b1", "w2", "b2", "w3", "b3"), top)}
+    w["lut"] = T(g["lut"])
+    eng = Q88Inference(w)
+    assert eng.mode == 0
+    assert np.array_equal(eng(T(iq)).cpu().numpy(), oq.infer_rows(iq, *top, g["lut"]))
+    # weights at the ends of what the digits hold (32639, -32768), ragged rows through the run walk of the matrix form
+    ext = [a.copy() for a in base]
+    ext[0][0, :4] = (32639, -32768, 32639, -32768)
+    ext[2][1, :2] = (32639, -32768)
+    ext[4][0, 0] = 32639
+    w = {k: T(a) for k, a in zip(("w1", "b1", "w2", "b2", "w3", "b3"), ext)}
+    w["lut"] = T(g["lut"])
+    eng = Q88Inference(w)
+    if eng.mode == 2:         # (the 32-bit proof may fail for such weights: then the 64-bit kernel serves them)
+        for shape in ((3, 203), (70, 69), (5, 1029), (33, 6)):
+            x = rng.integers(-32768, 32768, size=shape + (2,), dtype=np.int64).astype(np.int16)
+            assert np.array_equal(eng(T(x)).cpu().numpy(), oq.infer_rows(x, *ext, g["lut"])), shape
+    for shape in ((70, 69), (5, 1029), (33, 6), (1, 70), (2, 134)):
+        x = rng.integers(-32768, 32768, size=shape + (2,), dtype=np.int64).astype(np.int16)
+        w = {k: T(a) for k, a in zip(("w1", "b1", "w2", "b2", "w3", "b3"), base)}
+        w["lut"] = T(g["lut"])
+        assert np.array_equal(Q88Inference(w)(T(x)).cpu().numpy(), oq.infer_rows(x, *base, g["lut"])), shape
 
 
 def test_q88_export_from_generator():
