@@ -18,11 +18,25 @@ import torch
 import torch.distributed as dist
 
 
+def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
+    """all_reduce in place.  RCCL (backend "nccl") reduces device tensors directly.  Under gloo (CPU tests and the
+    one-GPU rehearsal of the multi-rank path) a device tensor is reduced through a host copy: gloo's own handling of
+    device tensors is not dependable on ROCm builds (observed: two ranks on one GPU stall inside all_reduce after a
+    few dozen calls), and the payloads here are a few kilobytes."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.detach().cpu()
+        dist.all_reduce(h, op=op, group=group)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+    return t
+
+
 class _GlobalSumFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, group):
         y = x.clone()
-        dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(y, dist.ReduceOp.SUM, group)
         return y
 
     @staticmethod
@@ -51,17 +65,17 @@ class DataParallel:
     # ---- collectives ----------------------------------------------------------------------
     def max_(self, t: torch.Tensor) -> torch.Tensor:
         if self.enabled:
-            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            _all_reduce(t, dist.ReduceOp.MAX, self.group)
         return t
 
     def sum_(self, t: torch.Tensor) -> torch.Tensor:
         if self.enabled:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            _all_reduce(t, dist.ReduceOp.SUM, self.group)
         return t
 
     def mean_(self, t: torch.Tensor) -> torch.Tensor:
         if self.enabled:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+            _all_reduce(t, dist.ReduceOp.SUM, self.group)
             t.div_(self.world)
         return t
 
@@ -77,7 +91,7 @@ class DataParallel:
         if not grads:
             return
         flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        _all_reduce(flat, dist.ReduceOp.SUM, self.group)
         off = 0
         for g in grads:
             n = g.numel()

@@ -640,6 +640,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))
+    if os.environ.get("DPD_BENCH_WATCHDOG"):      # debugging aid: dump every thread's stack if the run stalls
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["DPD_BENCH_WATCHDOG"]), exit=True)
     ctx = Ctx(args)
     if args.gpus != ctx.world and ctx.rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {ctx.world} rank(s); reporting n_gpus={ctx.world}", file=sys.stderr)

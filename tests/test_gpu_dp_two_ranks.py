@@ -67,3 +67,35 @@ def test_two_ranks_equal_one_process_on_the_concatenated_batch(tmp_path):
     close("s2_critic_grads", 3e-4, 3e-6 * float(one["s2_critic_grads"].abs().max()))
     close("s2_gen_grads", 3e-4, 3e-6 * float(one["s2_gen_grads"].abs().max()))
     close("s2_u", 1e-5, 1e-7)      # the power iteration sees weights only: the same on every rank
+
+
+def test_rccl_backend_one_rank(tmp_path):
+    """The transport the multi-GPU runs use (backend "nccl" = RCCL) in a child process with one rank: the process
+    group comes up on the GPU and the in-place reductions of parallel.py go through it on device tensors."""
+    code = r'''
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["DPD_ROOT"])
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+import dpd_amd
+from dpd_amd import parallel
+t = torch.arange(2945, dtype=torch.float32, device="cuda")
+parallel._all_reduce(t, dist.ReduceOp.SUM)
+m = torch.tensor([0.25], device="cuda")
+parallel._all_reduce(m, dist.ReduceOp.MAX)
+torch.cuda.synchronize()
+assert float(t.sum()) == 2944 * 2945 / 2 and float(m) == 0.25
+dist.barrier()
+dist.destroy_process_group()
+print("rccl ok")
+'''
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DPD_ROOT=os.path.dirname(HERE))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=150)
+    assert p.returncode == 0 and "rccl ok" in p.stdout, (p.stdout[-1500:], p.stderr[-3000:])
