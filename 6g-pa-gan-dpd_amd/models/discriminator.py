@@ -92,7 +92,11 @@ class SpectralNormLinear(nn.Module):
         self.linear = _SNLinearCore(in_features, out_features)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        return F.linear(x, self.linear.normalized_weight(self.training), self.linear.bias)
+        # The critic never calls its layers one by one: Discriminator.forward / mean_score run the four layers fused
+        # in the HIP kernels.  A single spectral-norm layer on its own has no kernel here, and this package has no
+        # torch fallback.
+        raise NotImplementedError("SpectralNormLinear runs only as part of Discriminator (the four layers are fused in "
+                                  "the HIP critic kernels); a stand-alone layer is not provided")
 
 
 class _CriticFn(torch.autograd.Function):

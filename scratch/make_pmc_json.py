@@ -21,5 +21,8 @@ for line in open(src):
         e["hbm_write_bytes"] = int(c["WRITE_SIZE"] * 1024)
         e["hbm_bytes"] = e["hbm_read_bytes"] + e["hbm_write_bytes"]
     res[name] = e
+if "w1024::k_stats" in res and "w1024::k_bwd" in res and "hbm_bytes" in res["w1024::k_stats"]:
+    res["spectral"] = {"hbm_bytes": res["w1024::k_stats"]["hbm_bytes"] + res["w1024::k_bwd"]["hbm_bytes"],
+                       "note": "k_stats + k_bwd, the two streaming kernels of SpectralLoss forward + backward"}
 json.dump(res, open(out, "w"), indent=1)
 print("wrote", out, len(res) - 2, "kernels")
