@@ -186,8 +186,8 @@ class CriticUpdate:
         dp.sum_(self.total)
         self.opt.step()
         s = self.sums
-        d_total = ((s[1] - s[0]) / N + self.gp_weight * s[2]) / dp.world
-        return dp.sum_(d_total)
+        # this rank's share of the critic loss (the caller sums the shares of all ranks, once per step)
+        return ((s[1] - s[0]) / N + self.gp_weight * s[2]) / dp.world
 
 
 class Stage2Step:
@@ -249,19 +249,25 @@ class Stage2Step:
         # running-scale bookkeeping of those forwards has to be repeated.
         fake = gen(iq)
         fake_d = fake.detach()
+        d_shares = []
         for it in range(self.n_critic):
             if it > 0 and hasattr(gen, "repeat_observation"):
                 gen.repeat_observation()
             alpha = alphas[it] if alphas is not None else None
             if self.critic_update is not None and target.dim() == 3:
-                info[f"d_total_{it}"] = self.critic_update(target, fake_d, cond, alpha)
+                d_shares.append(self.critic_update(target, fake_d, cond, alpha))
                 continue
             self.d_opt.zero_grad(set_to_none=True)
             d_total, d_info = self._critic_loss(target, fake_d, cond, alpha)
             d_total.backward()
             dp.sum_grads_(d_params)
             self.d_opt.step()
-            info[f"d_total_{it}"] = dp.sum_(d_total.detach().clone())
+            d_shares.append(d_total.detach())
+        # the critic losses of the step are only reported: one all-reduce for all of them
+        if d_shares:
+            d_all = dp.sum_(torch.stack(d_shares))
+            for it in range(self.n_critic):
+                info[f"d_total_{it}"] = d_all[it]
         self.g_opt.zero_grad(set_to_none=True)
         # the critic is frozen for the generator update: its parameter gradients would be discarded
         for p in d_params:
