@@ -1114,13 +1114,16 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
     const f32x4 w4 = quad(lds, Q_W4, lane);
     const int64_t ntiles = (N + 15) >> 4;
+    const unsigned tpr = ROW1 ? 1u : (unsigned)(L >> 4);      // tiles per row
     // the tile's input is loaded one tile ahead
     auto fetch = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
         float in = 0.f;
         if (tile < ntiles && n < N) {
             if (g < 2) {
-                const float al = alpha[ROW1 ? n : n / L];
+                // rows of L samples are whole tiles (L % 16 == 0, checked by the launcher): the row of a tile is one
+                // 32-bit division of wave-uniform values, not a 64-bit division per lane
+                const float al = alpha[ROW1 ? n : (int64_t)((unsigned)tile / tpr)];
                 in = al * real[2 * n + g] + (1.f - al) * fake[2 * n + g];
             } else {
                 in = cond[2 * n + g - 2];
@@ -1225,6 +1228,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
     FrontOps front;
     load_ops(front, lds, lane);
     const int64_t ntiles = (N + 15) >> 4;
+    const unsigned tpr = ROW1 ? 1u : (unsigned)(L >> 4);      // tiles per row
     // the tile's mask word, input gradient and row coefficient are loaded one tile ahead
     unsigned bits_next = 0u;
     float2 gh_next = make_float2(0.f, 0.f);
@@ -1236,7 +1240,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
             bits_next = maskw[tile * 64 + lane];
             if (n < N) {
                 const float2 gv = gin[n];
-                const float c = rowc[ROW1 ? n : n / L];
+                const float c = rowc[ROW1 ? n : (int64_t)((unsigned)tile / tpr)];      // whole tiles per row, as in pass A
                 gh_next = make_float2(c * gv.x, c * gv.y);
             }
         }
