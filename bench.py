@@ -8,7 +8,7 @@
 A step is one pass of the workload over one batch of synthetic OFDM-like IQ rows that is already
 resident in HBM (per GPU: 16384 rows of 1029 samples -> 2^24 generator outputs).
 
-Headline workload (`stage2`, BASELINE.json configs[2]): one CWGAN-GP training step -- 5 critic updates
+Headline workload (`stage2`, the configuration the metric is quoted on): one CWGAN-GP training step -- 5 critic updates
 (Wasserstein terms + gradient penalty with its double backward) and one generator update (adversarial +
 L1 + SpectralLoss with the row FFT), QAT generator, Adam.  The other workloads (Stage-1 step with and
 without QAT, Q8.8 integer inference, the generator -> PA chain forward and with its fused backward,
@@ -19,7 +19,7 @@ N > 1: one rank per GPU.  Launched by torch.distributed.run the ranks are alread
 plain `python bench.py --gpus N` this process starts them (before it touches a GPU) and passes the
 ranks' JSON line through.  Weak scaling by default (every rank holds its own 2^24 samples, rows are
 never exchanged, flat gradient buffers and QAT scales are all-reduced over RCCL).
-`--global-samples G` switches to a fixed global problem (BASELINE.json configs[3]: G = 2^28): G samples
+`--global-samples G` switches to a fixed global problem (the data-parallel configuration: G = 2^28): G samples
 are split over the ranks and one step is G / Bg optimiser steps on global batches of Bg samples
 (default 2^24), each with its gradient all-reduce; "scaling" is then "strong".
 Rank 0 prints one JSON line.

@@ -26,7 +26,7 @@ def _generator(qat, seed=11):
     return gen, params
 
 
-# ------------------------------------------------------------------ measured data (BASELINE configs[0])
+# ------------------------------------------------------------------ measured data (the CSV plumbing configuration)
 def test_csv_slice_through_the_chain():
     """First 4,096 rows of the reference's data/test_input.csv, normalised as train.py:80-83, through
     TDNNGeneratorQAT (eval) -> PADigitalTwin(add_noise=False) -> compute_metrics against the delayed,
