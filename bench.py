@@ -552,7 +552,7 @@ def cpu_q88(seq, budget=5.0):
             "sample": f"{reps} passes of {rows} rows x {seq} int16 samples with oracle/q88.py (numpy int64, one thread), ~{budget:.0f} s"}
 
 
-def cpu_gen_pa(seq, budget=5.0):
+def cpu_gen_pa(seq, budget=5.0, qat=True):
     import torch
     from oracle import generator as og
     from oracle import pa as opa
@@ -563,10 +563,33 @@ def cpu_gen_pa(seq, budget=5.0):
 
     def fn():
         with torch.no_grad():
-            return opa.volterra_forward(og.gen_forward(iq, gs.p, qat=True), cre, cim)
+            return opa.volterra_forward(og.gen_forward(iq, gs.p, qat=qat), cre, cim)
     reps, dt = _time_loop(fn, budget)
     return {"value": rows * (seq - 5) * reps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{reps} passes of QAT generator + PA twin over {rows} rows x {seq} samples with the vectorised oracle, ~{budget:.0f} s"}
+            "sample": f"{reps} passes of {'QAT' if qat else 'float'} generator + PA twin over {rows} rows x {seq} samples with the vectorised oracle, ~{budget:.0f} s"}
+
+
+def cpu_gen_pa_train(seq, budget=5.0):
+    """MSE on the PA output with autograd through PA twin and QAT generator (the oracle the fused chain backward is tested
+    against), gradients of the generator."""
+    import torch
+    from oracle import generator as og
+    from oracle import pa as opa
+    rows = 128
+    iq, target = _cpu_rows(rows, seq)
+    tgt = target[:, 4:, :] * 31.0
+    gs = _gen_state()
+    cre, cim = opa.init_coeffs()
+
+    def fn():
+        for p in gs.p.values():
+            p.grad = None
+        y = opa.volterra_forward(og.gen_forward(iq, gs.p, qat=True), cre, cim)
+        torch.nn.functional.mse_loss(y, tgt).backward()
+    reps, dt = _time_loop(fn, budget)
+    return {"value": rows * (seq - 5) * reps / dt, "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{reps} forward + backward passes of QAT generator -> PA twin -> MSE over {rows} rows x {seq} samples with the "
+                      f"oracle under torch autograd, ~{budget:.0f} s"}
 
 
 def cpu_gen_pa_literal(budget=6.0):
@@ -610,6 +633,7 @@ def cpu_spectral(seq, budget=3.0):
 CPU_BASELINES = {
     "stage2": lambda a: cpu_stage2(a.seq), "stage1": lambda a: cpu_stage1(False, a.seq), "stage1_qat": lambda a: cpu_stage1(True, a.seq),
     "q88": lambda a: cpu_q88(a.seq), "q88_stream": lambda a: cpu_q88(a.seq), "gen_pa": lambda a: cpu_gen_pa(a.seq),
+    "gen_pa_float": lambda a: cpu_gen_pa(a.seq, qat=False), "gen_pa_train": lambda a: cpu_gen_pa_train(a.seq),
     "spectral": lambda a: cpu_spectral(a.seq),
 }
 
@@ -678,7 +702,7 @@ def main():
             res["host"] = host_info()
             res["cpu_baseline"] = CPU_BASELINES[args.workload](args)
             if "extra" in res:
-                for name in ("stage1", "stage1_qat", "q88", "gen_pa", "spectral"):
+                for name in ("stage1", "stage1_qat", "q88", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral"):
                     if name in res["extra"]:
                         res["extra"][name]["cpu_baseline"] = CPU_BASELINES[name](args)
                 if "gen_pa" in res["extra"]:
