@@ -283,15 +283,20 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         }
         __syncthreads();
     }
-    f32x2 pac[PAF ? 4 : 1][PAF ? 5 : 1];   // (re, im) of coefficient [k][m], uniform: scalar registers
+    // (re, im) of coefficient [k][m]: orders 0..2 in scalar registers (uniform), the leading order in vector registers (a
+    // packed FMA takes one scalar operand: the first Horner step would otherwise need a copy)
+    f32x2 pac[PAF ? 3 : 1][PAF ? 5 : 1], pac3[PAF ? 5 : 1];
     if constexpr (PAF) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int m = 0; m < 5; ++m) {
 #pragma unroll
-            for (int m = 0; m < 5; ++m) {
+            for (int k = 0; k < 3; ++k) {
                 pac[k][m][0] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pa.cre[k * 5 + m])));
                 pac[k][m][1] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, pa.cim[k * 5 + m])));
             }
+            pac3[m] = f32x2{pa.cre[15 + m], pa.cim[15 + m]};
+            asm volatile("" : "+v"(pac3[m]));      // stays in vector registers
+        }
     }
     const int chunk_step = CARRY ? CHUNK : PAF ? CHUNK - 4 : PA ? CHUNK - (pa.M - 1) : CHUNK;   // outputs a chunk advances by
     // PA: the chunk's generator outputs (carry: behind the last four of the row's previous chunk)
@@ -443,6 +448,9 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         }
         if (chunk < n_chunks32) fetch(row, pos, fresh);
         __builtin_amdgcn_wave_barrier();
+        // scalar per chunk: outputs left in the row, base of the chunk's outputs (lanes add a 32-bit index)
+        const int rem = (int)(L - t0_cur < CHUNK ? L - t0_cur : CHUNK);
+        float2 *const orow = out ? out + (row_cur * L + t0_cur) : nullptr;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             if (t0_cur + 32 * p >= L) break;      // wave-uniform: the wave stays convergent
@@ -466,8 +474,9 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                     V2(B, vB, fB);
                     // lane (g, j): output g & 1 of sample j of tile g >> 1
                     float y = tanh_f32(fc3_pair(w3p, b3k, A.h2, B.h2));
-                    const int64_t t = t0_cur + 32 * p + 16 * (g >> 1) + j;
-                    if (QAT && !PA) amax = fmaxf(amax, t < L ? fabsf(y) : 0.f);
+                    const int tl = 32 * p + 16 * (g >> 1) + j;          // output index inside the chunk
+                    const bool in_row = tl < rem;                        // rem: outputs left in the row from t0_cur (scalar)
+                    if (QAT && !PA) amax = fmaxf(amax, in_row ? fabsf(y) : 0.f);
                     if (QAT && PA) y = fq16(y, s3);
                     // one row swap pairs the two outputs of a sample: rows 0 and 2 then store float2
                     const unsigned bits = __builtin_bit_cast(unsigned, y);
@@ -476,12 +485,12 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                     asm volatile("" : "+v"(u0), "+v"(u1));   // see the note on folded swap results in the backward kernel
                     const float2 yy = make_float2(__builtin_bit_cast(float, u0), __builtin_bit_cast(float, u1));
                     if (PA) {
-                        if (!odd) ybuf[YB0 + 32 * p + 16 * (g >> 1) + j] = yy;
+                        if (!odd) ybuf[YB0 + tl] = yy;
                         // generator outputs in the overlap belong to the next chunk of the row
-                        const bool mine = CARRY || t < t0_cur + chunk_step || t0_cur + chunk_step >= pa.OL;
-                        if (out && !odd && t < L && mine) out[row_cur * L + t] = yy;
+                        const bool mine = CARRY || tl < chunk_step || t0_cur + chunk_step >= pa.OL;
+                        if (out && !odd && in_row && mine) orow[tl] = yy;
                     } else {
-                        if (out && !odd && t < L) out[row_cur * L + t] = yy;
+                        if (out && !odd && in_row) orow[tl] = yy;
                     }
                 } else {
                     V2(B, vB, fB);
@@ -492,23 +501,28 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         }
         if constexpr (PAF) {
             __builtin_amdgcn_wave_barrier();
-            const int64_t n = t0_cur - YB0 + lane;               // PA output of this lane
-            if (lane < chunk_step && n >= 0 && n < pa.OL) {
+            // PA output of this lane: n = t0_cur - YB0 + lane; its bounds and the base of the stores are scalars
+            const int lane_lo = (CARRY && t0_cur == 0) ? YB0 : 0;
+            const int64_t left = pa.OL - (t0_cur - YB0);
+            const int lane_hi = (int)(left < chunk_step ? left : chunk_step);
+            if (lane >= lane_lo && lane < lane_hi) {
                 const f32x2 *const yb = reinterpret_cast<const f32x2 *>(ybuf);
+                f32x2 *const yrow = reinterpret_cast<f32x2 *>(pa.y + (row_cur * pa.OL + t0_cur - YB0));
                 f32x2 acc = {0.f, 0.f};
 #pragma unroll
                 for (int m = 0; m < 5; ++m) {
                     const f32x2 v = yb[lane + 4 - m];
                     const float pw = __builtin_fmaf(v[1], v[1], v[0] * v[0]);
                     const f32x2 pw2 = {pw, pw};
-                    f32x2 P = __builtin_elementwise_fma(pac[3][m], pw2, pac[2][m]);   // (Re, Im) of the tap polynomial, Horner in |u|^2
+                    f32x2 P = __builtin_elementwise_fma(pac3[m], pw2, pac[2][m]);   // (Re, Im) of the tap polynomial, Horner in |u|^2
                     P = __builtin_elementwise_fma(P, pw2, pac[1][m]);
                     P = __builtin_elementwise_fma(P, pw2, pac[0][m]);
-                    // acc += v * P (complex): (v.x P.re, v.x P.im) then (-v.y P.im, v.y P.re)
-                    acc = __builtin_elementwise_fma(f32x2{v[0], v[0]}, P, acc);
-                    acc = __builtin_elementwise_fma(f32x2{-v[1], v[1]}, f32x2{P[1], P[0]}, acc);
+                    // acc += v * P (complex): (v.x P.re, v.x P.im), then (-v.y P.im, v.y P.re) with the halves of v and P picked
+                    // and the sign applied by the instruction's own modifiers
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(acc) : "v"(v), "v"(P));
+                    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[1,0,0]" : "+v"(acc) : "v"(v), "v"(P));
                 }
-                pa.y[row_cur * pa.OL + n] = make_float2(acc[0], acc[1]);
+                yrow[lane] = acc;
             }
             __builtin_amdgcn_wave_barrier();
             if constexpr (CARRY) {
