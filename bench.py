@@ -686,7 +686,7 @@ LABELS = {
     "gen_pa_train": "generator -> PA twin with fused backward: MSE on the PA output, generator gradients, Adam; qat=on",
     "spectral": "SpectralLoss forward + backward",
 }
-EXTRAS = ("stage1", "stage1_qat", "q88", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral")
+EXTRAS = ("stage1", "stage1_qat", "q88", "q88_stream", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral")
 DTYPE = {"q88": "int16", "q88_stream": "int16", "stage2": "f32 (critic hidden-layer products: bf16 x 3-way split, fp32 accumulate)"}
 
 
@@ -721,10 +721,12 @@ def main():
         for name in EXTRAS:
             if name == args.workload:
                 continue
-            d, r, a = RUNNERS[name](ctx, args, 5, 2)
+            n_local = ctx.n_local
+            d, r, a = RUNNERS[name](ctx, args, 5, 2)          # (the stream workload sets its own samples per step)
             if ctx.rank == 0:
                 extra[name] = {"value": ctx.n_local * ctx.world * 5 / d, "unit": "samples/s", "ms_per_step": d / 5 * 1e3,
                                "steps": 5, "workload": LABELS[name], "roofline": r, **a}
+            ctx.n_local = n_local
         if ctx.rank == 0:
             res["extra"] = extra
     if ctx.rank == 0:
