@@ -70,10 +70,27 @@ constexpr int Q_W4 = 37;    //                e = r : W4[4g + r] (VALU operand)
 constexpr int NQUAD = 38;
 #endif
 constexpr int IMG_WORDS = NQUAD * 64 * 4;          // 9728
+// The weight gradients of the two inner layers (sums over the samples of a tile of h x d) on the bf16 matrix
+// cores as well: the three bf16 terms of both factors exist anyway (the forward and the chain split them), so
+// they are parked in LDS as [sample][neuron] slots and read back with the transposing ds_read_b64_tr_b16,
+// which hands a lane four consecutive samples of one neuron -- the operand layout of a product over samples.
+#ifndef CRITIC_OUTER_BF16
+#define CRITIC_OUTER_BF16 CRITIC_BF16X3
+#endif
+static_assert(!CRITIC_OUTER_BF16 || CRITIC_BF16X3, "the bf16 outer products take the split terms of the bf16 hidden layers");
 // per-wave transposition buffer
 constexpr int P64 = 80, P32 = 48, P16 = 16;        // row pitches: 16 mod 32 -> rows s, s+1 hit different bank halves
+#if CRITIC_OUTER_BF16
+// [p1 tile: 16 x P64 words, which the term slots of h2 / d2 (3) and d3 (2) share in time] [input tile] [h1 term slots (6)]
+constexpr int SLOT_B = 1024;                        // bytes of a slot: 16 samples x (two 16-neuron tiles x 4 neurons of a lane group) bf16
+constexpr int LEFT_W = 0, CONST_W = 16 * P64, H1_W = CONST_W + 16 * P16;
+constexpr int WAVE_WORDS = H1_W + 6 * SLOT_B / 4;  // 3072
+constexpr int S_H2 = 0, S_D2 = 0, S_D3 = 3 * SLOT_B, S_H1 = 4 * H1_W;   // byte offsets of the slot groups in the wave's buffer
+static_assert(5 * SLOT_B <= 4 * 16 * P64, "the h2 / d2 / d3 slots lie inside the p1 tile");
+#else
 constexpr int LEFT_W = 0, RIGHT_W = 16 * P64, CONST_W = RIGHT_W + 16 * P32;
 constexpr int WAVE_WORDS = CONST_W + 16 * P16;     // 2304
+#endif
 constexpr int LDS_WORDS = IMG_WORDS + WG_WAVES * WAVE_WORDS;
 static_assert(LDS_WORDS >= WG_WAVES * C_SLAB, "gradient rows are combined in the same LDS");
 
@@ -322,9 +339,14 @@ DEV void load_ops(BotOps &o, const float *img, int lane) {
 // z0, z1 += W2 (rows 0..15 | 16..31) x src, src = 64 values per sample in four quads, two k-steps of 32.
 // ACT: src holds FC1 pre-activations; LeakyReLU is applied on the way in.  pre() runs before the second
 // k-step.  The splits and activations of the second step sit in the shadow of the first step's MFMAs.
-template <bool ACT, bool BITS, class Pre>
+struct NoKeep {        // the split terms of a factor are not wanted
+    DEV void operator()(int, const B3 &) const {}
+    DEV void operator()(const B3 &) const {}
+    DEV void operator()(const unsigned (&)[2], const unsigned (&)[2], const unsigned (&)[2]) const {}
+};
+template <bool ACT, bool BITS, class Pre, class Keep = NoKeep>
 DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], const B3 (&w)[2], f32x4 (&m)[4], unsigned &bits,
-                   const float *img, int lane, float slope, Pre pre, unsigned long long *ts = nullptr) {
+                   const float *img, int lane, float slope, Pre pre, unsigned long long *ts = nullptr, Keep keep = Keep()) {
     if (ACT) {
         act4<BITS>(src[0], slope, src[0], m[0], bits, 0);
         act4<BITS>(src[1], slope, src[1], m[1], bits, 4);
@@ -333,6 +355,7 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], const B3 (&w)[2], f32x
     load_b3(n[0], img, QB_A2 + 3, lane);
     load_b3(n[1], img, QB_A2 + 9, lane);
     split8(b, src[0], src[1]);
+    keep(0, b);
     FENCE();
     f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
     mfma6(y0, z0, w[0], b);
@@ -343,6 +366,7 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], const B3 (&w)[2], f32x
     }
     B3 b2;
     split8(b2, src[2], src[3]);
+    keep(1, b2);
     TS(2)
     FENCE();
     pre();
@@ -356,36 +380,38 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], const B3 (&w)[2], f32x
 }
 
 // forward of one tile; `in` = input component g of sample j (x0, x1, c0, c1 by lane group).
-template <bool BITS = false, class Pre>
+template <bool BITS = false, class Pre, class Keep = NoKeep>
 DEV void forward_front(Acts &a, const float *img, int lane, float in, float slope, const FrontOps &o, Pre pre,
-                       unsigned long long *ts = nullptr) {
+                       unsigned long long *ts = nullptr, Keep keep = Keep()) {
     a.bits = 0u;
     TS(0)
 #pragma unroll
     for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, o.b1[t]);
     TS(1)
     f32x4 z0 = o.b2[0], z1 = o.b2[1];
-    fc2_block<true, BITS>(z0, z1, a.h1, o.w, a.m1, a.bits, img, lane, slope, pre, ts);
+    fc2_block<true, BITS>(z0, z1, a.h1, o.w, a.m1, a.bits, img, lane, slope, pre, ts, keep);
     act4<BITS>(z0, slope, a.h2[0], a.m2[0], a.bits, 16);
     act4<BITS>(z1, slope, a.h2[1], a.m2[1], a.bits, 20);
     TS(6)
 }
 // y = W3 x (16 outputs from the 32 values of a tile pair), on top of `start`
-DEV f32x4 fc3_product(const f32x4 &x0, const f32x4 &x1, const B3 &w, f32x4 start) {
+template <class Keep = NoKeep>
+DEV f32x4 fc3_product(const f32x4 &x0, const f32x4 &x1, const B3 &w, f32x4 start, Keep keep = Keep()) {
     B3 b;
     split8(b, x0, x1);
+    keep(b);
     f32x4 lo = {0.f, 0.f, 0.f, 0.f};
     mfma6(lo, start, w, b);
     return start + lo;
 }
 // FC3 and the last layer (16 -> 1), which runs on the VALU: four FMAs per lane and a sum over the lane groups
-template <bool BITS = false, class Pre>
+template <bool BITS = false, class Pre, class Keep = NoKeep>
 DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc3Ops &o, Pre pre,
-                      unsigned long long *ts = nullptr) {
+                      unsigned long long *ts = nullptr, Keep keep = Keep()) {
     TS(7)
     pre();
     FENCE();
-    const f32x4 y = fc3_product(a.h2[0], a.h2[1], o.w, o.b3);
+    const f32x4 y = fc3_product(a.h2[0], a.h2[1], o.w, o.b3, keep);
     FENCE();
     TS(8)
     act4<BITS>(y, slope, a.h3, a.m3, a.bits, 24);
@@ -399,13 +425,14 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
 // back-propagation of an upstream vector through the three hidden layers, in two steps:
 //   top[r] (16 values on neurons 4g + r of layer 3, already masked) -> d2[2] (layer 2, masked) -> d1[4] (layer 1, masked)
 // The first step contracts over 16 neurons: v_mfma_f32_16x16x16_bf16, whose k = 4g + e is what a lane holds.
-template <class Pre>
-DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps &o, Pre pre) {
+template <class Pre, class Keep = NoKeep>
+DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps &o, Pre pre, Keep keep = Keep()) {
     pre();
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     unsigned bh[2], bm[2], bl[2];
     split_pair(top[0], top[1], bh[0], bm[0], bl[0]);
     split_pair(top[2], top[3], bh[1], bm[1], bl[1]);
+    keep(bh, bm, bl);
     const s16x4 b[3] = {__builtin_bit_cast(s16x4, u32x2{bh[0], bh[1]}), __builtin_bit_cast(s16x4, u32x2{bm[0], bm[1]}),
                         __builtin_bit_cast(s16x4, u32x2{bl[0], bl[1]})};
     FENCE();
@@ -424,13 +451,14 @@ DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps
     d2[1] = e1 * m2[1];
 }
 // pre() runs before the second half
-template <class Pre>
+template <class Pre, class Keep = NoKeep>
 DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f32x4 (&m1)[4], f32x4 (&d1)[4], const BotOps &o,
-                      Pre pre) {
+                      Pre pre, Keep keep = Keep()) {
     B3 w2[2], b;
     load_b3(w2[0], img, QB_A2T + 6, lane);
     load_b3(w2[1], img, QB_A2T + 9, lane);
     split8(b, d2[0], d2[1]);
+    keep(b);
     FENCE();
     f32x4 f[4], flo[4];
 #pragma unroll
@@ -636,9 +664,17 @@ struct Accum {
 
 // LDS addresses of this lane inside its wave's transposition buffer, wave base included: every access is
 // one register plus an immediate offset (no address arithmetic in the tile loop)
+typedef __attribute__((address_space(3))) char lds_char;
 struct Addr {
-    char *wl64, *wl32, *wr32, *wr16;     // this lane's float4 stores (row j, columns 4g..)
+    char *wl64;                          // p1: this lane's float4 stores (row j, columns 4g..)
+#if CRITIC_OUTER_BF16
+    char *tw;                            // term slots: this lane's 16 bytes of row j (chunk g, swizzled)
+    lds_char *tr;                        // term slots: the 8 bytes this lane points the transposing read at
+    lds_char *tr2, *tr3;                 // the same address again, opaque to the compiler (see read_op)
+#else
+    char *wl32, *wr32, *wr16;            // this lane's float4 stores (row j, columns 4g..)
     char *rl64[4], *rl32[4], *rr32[4], *rr16[4];   // operand reads for k-step q (row 4q + g, column j)
+#endif
     char *row64[4];                      // p1: word lane ^ 4k of a left64 row (k = swizzle class of the row)
     char *col4;                          // p1: column lane & 3 of the constant region
     char *cst;                           // this lane's word of the constant region: column g of row j
@@ -646,6 +682,21 @@ struct Addr {
 
 DEV void make_addr(Addr &ad, char *wb, int j, int g) {
     ad.wl64 = wb + 4 * (LEFT_W + j * P64 + ((4 * g) ^ swz(j)));
+#if CRITIC_OUTER_BF16
+    // A slot is 16 rows (samples) of 64 bytes; chunk c of a row holds neurons 4c..4c+3 of an even tile and of the
+    // next one, 8 bytes each.  The chunk index is XORed with bits 1..2 of the row: the 8 lanes of a 16-byte
+    // store group then cover all 32 banks.  The transposing read of lane group kg takes rows 4kg..4kg+3:
+    // lane 4q + p of the group points at chunk p of row 4kg + q (two-way bank conflict between rows r, r + 4).
+    ad.tw = wb + 64 * j + 16 * (g ^ ((j >> 1) & 3));
+    {
+        const int row = 4 * g + (j >> 2), p = j & 3;
+        ad.tr = (lds_char *)(wb + 64 * row + 16 * (p ^ ((row >> 1) & 3)));
+        ad.tr2 = ad.tr;
+        ad.tr3 = ad.tr;
+        asm("" : "+v"(ad.tr2));
+        asm("" : "+v"(ad.tr3));
+    }
+#else
     ad.wl32 = wb + 4 * (LEFT_W + j * P32 + ((4 * g) ^ swz(j)));
     ad.wr32 = wb + 4 * (RIGHT_W + j * P32 + ((4 * g) ^ swz(j)));
     ad.wr16 = wb + 4 * (RIGHT_W + j * P16 + ((4 * g) ^ swz(j)));
@@ -657,6 +708,7 @@ DEV void make_addr(Addr &ad, char *wb, int j, int g) {
         ad.rr32[q] = wb + 4 * (RIGHT_W + s * P32 + c);
         ad.rr16[q] = wb + 4 * (RIGHT_W + s * P16 + c);
     }
+#endif
     const int lane = 16 * g + j;
 #pragma unroll
     for (int k = 0; k < 4; ++k) ad.row64[k] = wb + 4 * (LEFT_W + (lane ^ (4 * k)));
@@ -700,6 +752,68 @@ DEV void mfma_p1(Accum &ac, const P1R &o) {
         if (s & 1) ac.p1_sum += f32x2{o.l[s - 1], o.l[s]};
     }
 }
+#if CRITIC_OUTER_BF16
+// ---- p2, p3 on the bf16 matrix cores ------------------------------------------------------------------
+// x = h + m + l on both sides; the six products a K = 32 instruction needs three MFMAs for, two products
+// each: the 8 k-slots of a lane group are four samples of one term and the same four samples of another.
+//   [h|l] x [l|h] = hl + lh,  [h|m] x [m|h] = hm + mh,  [h|m] x [h|m] = hh + mm      (left term first)
+struct OpL { bf16x8 hm, hl; };          // left factor (rows of the result): [h|m], [h|l]
+struct OpR { bf16x8 hm, mh, lh; };      // right factor (columns): [h|m], [m|h], [l|h]
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+DEV s16x4 tr_read(lds_char *p) { return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p); }
+DEV bf16x8 cat(s16x4 a, s16x4 b) {
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    return __builtin_bit_cast(bf16x8, (s16x8)__builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// h, m, l: byte offsets of the 8-byte pieces of the three terms.  A term that goes into several operands is read
+// once per operand, through a copy of the address the compiler cannot see through: merged into one read, the
+// value would have to be copied into place with VALU moves, and an LDS read is the cheaper instruction here.
+DEV void read_op(OpL &o, const Addr &ad, int h, int m, int l) {
+    o.hm = cat(tr_read(ad.tr + h), tr_read(ad.tr + m));
+    o.hl = cat(tr_read(ad.tr2 + h), tr_read(ad.tr + l));
+}
+DEV void read_op(OpR &o, const Addr &ad, int h, int m, int l) {
+    o.hm = cat(tr_read(ad.tr + h), tr_read(ad.tr + m));
+    o.mh = cat(tr_read(ad.tr2 + m), tr_read(ad.tr2 + h));
+    o.lh = cat(tr_read(ad.tr + l), tr_read(ad.tr3 + h));
+}
+// tile (0 or 1) of a parked pair of tiles: slot group at byte offset `base`, one slot per term
+template <class Op>
+DEV void read_pair_op(Op &o, const Addr &ad, int base, int tile) {
+    read_op(o, ad, base + 8 * tile, base + SLOT_B + 8 * tile, base + 2 * SLOT_B + 8 * tile);
+}
+// (stored as float vectors like everything else in this buffer: the slots share memory with the p1 tile, and
+// accesses of one type keep their program order)
+DEV void park_b3(const Addr &ad, int base, const B3 &b) {
+    ST4(ad.tw, base, __builtin_bit_cast(f32x4, b.h));
+    ST4(ad.tw, base + SLOT_B, __builtin_bit_cast(f32x4, b.m));
+    ST4(ad.tw, base + 2 * SLOT_B, __builtin_bit_cast(f32x4, b.l));
+    __builtin_amdgcn_wave_barrier();
+}
+// one 16-neuron tile: [h|m] in the first slot, l in the first half of the second
+DEV void park_single(const Addr &ad, int base, const unsigned (&h)[2], const unsigned (&m)[2], const unsigned (&l)[2]) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    ST4(ad.tw, base, __builtin_bit_cast(f32x4, u32x4{h[0], h[1], m[0], m[1]}));
+    *reinterpret_cast<f32x2 *>(ad.tw + base + SLOT_B) = __builtin_bit_cast(f32x2, u32x2{l[0], l[1]});
+    __builtin_amdgcn_wave_barrier();
+}
+DEV void read_single_op(OpR &o, const Addr &ad, int base) { read_op(o, ad, base, base + 8, base + SLOT_B); }
+DEV void outer3(f32x4 &acc, const OpL &a, const OpR &b) {
+    acc = mfma_bf(a.hl, b.lh, acc);
+    acc = mfma_bf(a.hm, b.mh, acc);
+    acc = mfma_bf(a.hm, b.hm, acc);
+}
+// both right tiles against one left tile, the two accumulator chains interleaved
+DEV void outer3x2(f32x4 &acc0, f32x4 &acc1, const OpL &a, const OpR &b0, const OpR &b1) {
+    acc0 = mfma_bf(a.hl, b0.lh, acc0);
+    acc1 = mfma_bf(a.hl, b1.lh, acc1);
+    acc0 = mfma_bf(a.hm, b0.mh, acc0);
+    acc1 = mfma_bf(a.hm, b1.mh, acc1);
+    acc0 = mfma_bf(a.hm, b0.hm, acc0);
+    acc1 = mfma_bf(a.hm, b1.hm, acc1);
+}
+#else
 DEV void park_p2(const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) ST4(ad.wl64, 64 * t, left[t]);
@@ -754,6 +868,7 @@ DEV void mfma_p3(Accum &ac, const P3R &o) {
         ac.p3[1] = mfma4(o.l1[q], o.r[q], ac.p3[1]);
     }
 }
+#endif
 
 DEV void zero_accum(Accum &ac) {
     const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -992,14 +1107,104 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
         BotOps bot;
         InOps ino;
         P1R p1r;
-        P2R p2r;
-        P3R p3r;
 #ifdef ABL_TIMING
         fts[15] = __builtin_readcyclecounter();
         unsigned long long *const ftp = fts;
 #else
         unsigned long long *const ftp = nullptr;
 #endif
+#if CRITIC_OUTER_BF16
+        // The factors of the two inner weight gradients are parked as the bf16 terms the products split them
+        // into anyway -- h1 in FC2, h2 in FC3, gz3 and gz2 in the chain -- and come back transposed right before
+        // the chain step whose MFMAs cover the read: p3 (h2 x gz3) after the top of the chain, p2 (h1 x gz2)
+        // after its bottom, one h1 tile ahead.
+        OpL h2l[2], h1l[2];
+        OpR d3r, d2r[2];
+        forward_front(a, lds, lane, in, slope, front, [&] {
+            load_ops(o3, lds, lane);
+            if (WGRAD) read_p1(p1r, ad);   // previous tile's W1 gradient: parked a whole forward ago
+        }, ftp, [&](int half, const B3 &b) {
+            if (WGRAD) park_b3(ad, S_H1 + 3 * SLOT_B * half, b);
+        });
+        if (WGRAD) mfma_p1(ac, p1r);
+        forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); }, ftp, [&](const B3 &b) {
+            if (WGRAD) park_b3(ad, S_H2, b);     // after read_p1: the slots lie inside the p1 tile
+        });
+        STAMP(1)
+        ssum += (valid && g == 0) ? a.score : 0.f;
+        const f32x4 (&m1)[4] = a.m1;
+        const f32x4 (&m2)[2] = a.m2;
+        const f32x4 gz3 = w4 * gs * a.m3;
+        f32x4 gz2[2], gz1[4];
+        chain_top(gz3, m2, gz2, top, [&] { load_ops(bot, lds, lane); },
+                  [&](const unsigned (&bh)[2], const unsigned (&bm)[2], const unsigned (&bl)[2]) {
+                      if (WGRAD) {
+                          park_single(ad, S_D3, bh, bm, bl);
+                          read_pair_op(h2l[0], ad, S_H2, 0);
+                          read_pair_op(h2l[1], ad, S_H2, 1);
+                          read_single_op(d3r, ad, S_D3);
+                          __builtin_amdgcn_wave_barrier();
+                      }
+                  });
+        if (WGRAD) {
+            ac.p3[0] = mfma_bf(h2l[0].hl, d3r.lh, ac.p3[0]);
+            ac.p3[1] = mfma_bf(h2l[1].hl, d3r.lh, ac.p3[1]);
+            ac.p3[0] = mfma_bf(h2l[0].hm, d3r.mh, ac.p3[0]);
+            ac.p3[1] = mfma_bf(h2l[1].hm, d3r.mh, ac.p3[1]);
+            ac.p3[0] = mfma_bf(h2l[0].hm, d3r.hm, ac.p3[0]);
+            ac.p3[1] = mfma_bf(h2l[1].hm, d3r.hm, ac.p3[1]);
+            db2[0] += gz2[0];
+            db2[1] += gz2[1];
+        }
+        chain_bottom(lds, lane, gz2, m1, gz1, bot, [&] {
+            if (WGRAD) {
+                read_pair_op(d2r[0], ad, S_D2, 0);
+                read_pair_op(d2r[1], ad, S_D2, 1);
+                read_pair_op(h1l[0], ad, S_H1, 0);
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (DX) load_ops(ino, lds, lane);
+        }, [&](const B3 &b) {
+            if (WGRAD) park_b3(ad, S_D2, b);     // the h2 slots: their reads are issued
+        });
+        STAMP(2)
+        load_ops(front, lds, lane);          // next tile
+        FENCE();
+        if (WGRAD) {
+            // (the fences keep every read one MFMA group ahead of its use)
+            read_pair_op(h1l[1], ad, S_H1, 1);
+            FENCE();
+            outer3x2(ac.p2[0][0], ac.p2[0][1], h1l[0], d2r[0], d2r[1]);
+            FENCE();
+            read_pair_op(h1l[0], ad, S_H1 + 3 * SLOT_B, 0);
+            FENCE();
+            outer3x2(ac.p2[1][0], ac.p2[1][1], h1l[1], d2r[0], d2r[1]);
+            FENCE();
+            read_pair_op(h1l[1], ad, S_H1 + 3 * SLOT_B, 1);
+            FENCE();
+            outer3x2(ac.p2[2][0], ac.p2[2][1], h1l[0], d2r[0], d2r[1]);
+            FENCE();
+            outer3x2(ac.p2[3][0], ac.p2[3][1], h1l[1], d2r[0], d2r[1]);
+            __builtin_amdgcn_wave_barrier();
+            STAMP(4)
+        }
+        if (DX) {
+            float g0, g1;
+            to_input(gz1, g0, g1, ino);
+            if (valid && g == 0) gx[n] = make_float2(g0, g1);
+        }
+        if (WGRAD) {
+            db3 += gz3;
+            dw4 += a.h3 * gs;
+            db4 += gs;
+            // the input tile: column g of row j
+            *reinterpret_cast<float *>(ad.cst) = in;
+            park_p1(ad, gz1);
+            STAMP(3)
+        }
+#else
+        P2R p2r;
+        P3R p3r;
         forward_front(a, lds, lane, in, slope, front, [&] {
             load_ops(o3, lds, lane);
             if (WGRAD) read_p1(p1r, ad);   // previous tile's W1 gradient: parked a whole forward ago
@@ -1051,6 +1256,7 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
             park_p1(ad, gz1);
             STAMP(3)
         }
+#endif
     }
     if (WGRAD) {
         P1R p1r;
@@ -1287,13 +1493,70 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         TopOps top;
         BotOps bot;
         P1R p1r;
-        P2R p2r;
-        P3R p3r;
         unsigned no_bits = 0u;
         auto pre_fc2 = [&] {
             load_ops(o3, lds, lane);
             read_p1(p1r, ad);           // previous tile's v1 x gh
         };
+#if CRITIC_OUTER_BF16
+        // as in the backward kernel: p3 = du2 x v3 after the top of the chain, p2 = du1 x v2 after its bottom, the
+        // factors parked as the bf16 terms of the products that consume them
+        OpL du2l[2], du1l[2];
+        OpR v3r, v2r[2];
+        fc2_block<false, false>(z0, z1, du1, front.w, m1, no_bits, lds, lane, slope, pre_fc2, nullptr,
+                                [&](int half, const B3 &b) { park_b3(ad, S_H1 + 3 * SLOT_B * half, b); });
+        mfma_p1(ac, p1r);
+        f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
+        load_ops(top, lds, lane);
+        FENCE();
+        // dv3 = W3 du2 ; dW4 += dv3 * D3
+        const f32x4 dv3 = fc3_product(du2[0], du2[1], o3.w, f32x4{0.f, 0.f, 0.f, 0.f},
+                                      [&](const B3 &b) { park_b3(ad, S_H2, b); });      // after read_p1: inside the p1 tile
+        FENCE();
+        dw4 += dv3 * m3;
+        chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); },
+                  [&](const unsigned (&bh)[2], const unsigned (&bm)[2], const unsigned (&bl)[2]) {
+                      park_single(ad, S_D3, bh, bm, bl);
+                      read_pair_op(du2l[0], ad, S_H2, 0);
+                      read_pair_op(du2l[1], ad, S_H2, 1);
+                      read_single_op(v3r, ad, S_D3);
+                      __builtin_amdgcn_wave_barrier();
+                  });
+        ac.p3[0] = mfma_bf(du2l[0].hl, v3r.lh, ac.p3[0]);
+        ac.p3[1] = mfma_bf(du2l[1].hl, v3r.lh, ac.p3[1]);
+        ac.p3[0] = mfma_bf(du2l[0].hm, v3r.mh, ac.p3[0]);
+        ac.p3[1] = mfma_bf(du2l[1].hm, v3r.mh, ac.p3[1]);
+        ac.p3[0] = mfma_bf(du2l[0].hm, v3r.hm, ac.p3[0]);
+        ac.p3[1] = mfma_bf(du2l[1].hm, v3r.hm, ac.p3[1]);
+        chain_bottom(lds, lane, v2, m1, v1, bot, [&] {
+            read_pair_op(v2r[0], ad, S_D2, 0);
+            read_pair_op(v2r[1], ad, S_D2, 1);
+            read_pair_op(du1l[0], ad, S_H1, 0);
+            __builtin_amdgcn_wave_barrier();
+        }, [&](const B3 &b) { park_b3(ad, S_D2, b); });      // the du2 slots: their reads are issued
+        load_ops(front, lds, lane);           // next tile
+        FENCE();
+        // (the fences keep every read one MFMA group ahead of its use)
+        read_pair_op(du1l[1], ad, S_H1, 1);
+        FENCE();
+        outer3x2(ac.p2[0][0], ac.p2[0][1], du1l[0], v2r[0], v2r[1]);
+        FENCE();
+        read_pair_op(du1l[0], ad, S_H1 + 3 * SLOT_B, 0);
+        FENCE();
+        outer3x2(ac.p2[1][0], ac.p2[1][1], du1l[1], v2r[0], v2r[1]);
+        FENCE();
+        read_pair_op(du1l[1], ad, S_H1 + 3 * SLOT_B, 1);
+        FENCE();
+        outer3x2(ac.p2[2][0], ac.p2[2][1], du1l[0], v2r[0], v2r[1]);
+        FENCE();
+        outer3x2(ac.p2[3][0], ac.p2[3][1], du1l[1], v2r[0], v2r[1]);
+        __builtin_amdgcn_wave_barrier();
+        // gh tile: column g (< 2) of row j
+        if (g < 2) *reinterpret_cast<float *>(ad.cst) = ghb;
+        park_p1(ad, v1);
+#else
+        P2R p2r;
+        P3R p3r;
 #if CRITIC_BF16X3
         fc2_block<false, false>(z0, z1, du1, front.w, m1, no_bits, lds, lane, slope, pre_fc2);
 #else
@@ -1331,6 +1594,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         // gh tile: column g (< 2) of row j
         if (g < 2) *reinterpret_cast<float *>(ad.cst) = ghb;
         park_p1(ad, v1);
+#endif
     }
     {
         P1R p1r;
