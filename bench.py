@@ -44,10 +44,11 @@ CRITIC_FWD_MAC, CRITIC_BWD_MAC, CRITIC_DX_MAC = 2832, 5408, 2704
 PA_FLOP = 200                                   # memory polynomial, 4 orders x 5 taps (complex Horner form)
 PA_BWD_FLOP = 400
 # MFMA instructions the critic's fused mean-score pass (forward + backward) issues per tile of 16 samples, with
-# their issue cycles per SIMD (counted in the kernel's assembly): the fp32 products run on
-# v_mfma_f32_16x16x4_f32 (32 cycles) and v_mfma_f32_4x4x1_16b_f32 (8), the hidden-layer products as three-way-split
-# bf16 operands on v_mfma_f32_16x16x32_bf16 (16) and v_mfma_f32_16x16x16_bf16 (8)
-CRITIC_BWD_MFMA_CYCLES = 44 * 32 + 16 * 8 + 54 * 16 + 12 * 8
+# their issue cycles per SIMD (counted in the kernel's assembly): FC1 runs on v_mfma_f32_16x16x4_f32 (4 x 32 cycles) and
+# the first-layer weight gradient on v_mfma_f32_4x4x1_16b_f32 (16 x 8); the hidden-layer products (54) and the weight
+# gradients of the two inner layers (30) as three-way-split bf16 operands on v_mfma_f32_16x16x32_bf16 (16 cycles), the
+# contraction over the 16 layer-3 neurons on v_mfma_f32_16x16x16_bf16 (12, priced at their peak rate of 8)
+CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + 84 * 16 + 12 * 8
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
 
@@ -272,8 +273,8 @@ def run_stage2(ctx, args, steps, warmup):
     issue_s = tiles_per_simd * CRITIC_BWD_MFMA_CYCLES / CLOCK_HZ
     roof = {"bound": "mfma",
             "kernel": "k_critic_bwd_mfma<true,false>: critic forward + backward with weight gradients in one pass "
-                      "(10 of the step's launches); fp32 MFMA for FC1 and the outer products, hidden-layer products as "
-                      "3-way-split bf16 operands on the bf16 MFMA (fp32 accuracy)",
+                      "(10 of the step's launches); fp32 MFMA for FC1 and the first-layer weight gradient, hidden-layer "
+                      "products and the inner weight gradients as 3-way-split bf16 operands on the bf16 MFMA (fp32 accuracy)",
             # algorithmic flops of the pass (2 x (2,832 + 5,408) MAC per sample) over the measured kernel time, against the
             # fp32 peak: the arithmetic is fp32-accurate, whichever matrix pipe carries it
             "achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kflop / k / 1e12 / FP32_PEAK_TFLOPS,
@@ -687,7 +688,7 @@ LABELS = {
     "spectral": "SpectralLoss forward + backward",
 }
 EXTRAS = ("stage1", "stage1_qat", "q88", "q88_stream", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral")
-DTYPE = {"q88": "int16", "q88_stream": "int16", "stage2": "f32 (critic hidden-layer products: bf16 x 3-way split, fp32 accumulate)"}
+DTYPE = {"q88": "int16", "q88_stream": "int16", "stage2": "f32 (critic hidden-layer products and inner weight gradients: bf16 x 3-way split, fp32 accumulate)"}
 
 
 def main():
