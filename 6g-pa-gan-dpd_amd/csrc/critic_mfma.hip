@@ -1325,6 +1325,9 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
     auto fetch = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
         float in = 0.f;
+#ifdef ABL_GPA_NOLOAD      // experiment: no global loads in the loop
+        if (tile < ntiles) return 0.01f * (float)lane + 0.1f * (float)(tile & 7);
+#endif
         if (tile < ntiles && n < N) {
             if (g < 2) {
                 // rows of L samples are whole tiles (L % 16 == 0, checked by the launcher): the row of a tile is one
@@ -1370,6 +1373,9 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         float g0, g1;
         to_input(v1, g0, g1, ino);
         if (!valid) { g0 = 0.f; g1 = 0.f; }
+#ifdef ABL_GPA_NOSTORE     // experiment: no global stores in the loop (the condition never holds)
+        if (bits != 0x12345678u || g0 != 1.2345f) continue;
+#endif
         maskw[tile * 64 + lane] = bits;
         if (valid && g == 0) gout[n] = make_float2(g0, g1);
         if (!ROW1) {
