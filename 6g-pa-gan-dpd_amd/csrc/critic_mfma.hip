@@ -228,6 +228,17 @@ DEV float sum_over_groups(float v) {
 // earlier, so the LDS latency of a read is covered by the MFMAs of the group before it.  The fences keep
 // the compiler from sinking those reads down to their first use.
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
+// issue priority of the wave around a burst of matrix instructions (experiment switch CRITIC_SETPRIO)
+#ifndef CRITIC_SETPRIO
+#define CRITIC_SETPRIO 0
+#endif
+#if CRITIC_SETPRIO
+#define PRIO_UP() __builtin_amdgcn_s_setprio(CRITIC_SETPRIO)
+#define PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#else
+#define PRIO_UP()
+#define PRIO_DOWN()
+#endif
 // experiment hook: ts == NULL in every product build (the code folds away); a timing build passes an
 // array whose slot 15 holds the last stamp
 #define TS(k)                                                      \
@@ -291,12 +302,14 @@ DEV void split8(B3 &o, const f32x4 &x0, const f32x4 &x1) {
 DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 // c + a x b to fp32 accuracy: two chains of three products each, small terms first
 DEV void mfma6(f32x4 &lo, f32x4 &hi, const B3 &a, const B3 &b) {
+    PRIO_UP();
     lo = mfma_bf(a.m, b.m, lo);
     hi = mfma_bf(a.m, b.h, hi);
     lo = mfma_bf(a.l, b.h, lo);
     hi = mfma_bf(a.h, b.m, hi);
     lo = mfma_bf(a.h, b.l, lo);
     hi = mfma_bf(a.h, b.h, hi);
+    PRIO_DOWN();
 }
 
 struct FrontOps {      // FC1 weights and accumulator start (b1), FC2 accumulator start (b2), FC2 weights of the first k-step
@@ -439,6 +452,7 @@ DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
     // products in the order mm, lh, hl, mh, hm, hh (term of the weights, term of the activations)
     const int ta[6] = {1, 2, 0, 1, 0, 0}, tb[6] = {1, 0, 2, 0, 1, 0};
+    PRIO_UP();
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
         typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -446,6 +460,7 @@ DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps
         e0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[0], w[1], w[2], w[3]}, b[tb[k]], e0, 0, 0, 0);
         e1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[4], w[5], w[6], w[7]}, b[tb[k]], e1, 0, 0, 0);
     }
+    PRIO_DOWN();
     FENCE();
     d2[0] = e0 * m2[0];
     d2[1] = e1 * m2[1];
@@ -806,12 +821,14 @@ DEV void outer3(f32x4 &acc, const OpL &a, const OpR &b) {
 }
 // both right tiles against one left tile, the two accumulator chains interleaved
 DEV void outer3x2(f32x4 &acc0, f32x4 &acc1, const OpL &a, const OpR &b0, const OpR &b1) {
+    PRIO_UP();
     acc0 = mfma_bf(a.hl, b0.lh, acc0);
     acc1 = mfma_bf(a.hl, b1.lh, acc1);
     acc0 = mfma_bf(a.hm, b0.mh, acc0);
     acc1 = mfma_bf(a.hm, b1.mh, acc1);
     acc0 = mfma_bf(a.hm, b0.hm, acc0);
     acc1 = mfma_bf(a.hm, b1.hm, acc1);
+    PRIO_DOWN();
 }
 #else
 DEV void park_p2(const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
@@ -980,6 +997,24 @@ struct TileQueue {
     }
 };
 
+// experiment hook: ABL_EXTRA_VALU / ABL_EXTRA_MFMA extra independent instructions per tile (what a kernel's time
+// does with them tells which unit bounds it); nothing in a product build
+DEV void abl_extra(float &d0, float &d1, float &d2, float &d3, f32x4 &dm) {
+#ifdef ABL_EXTRA_VALU
+#pragma unroll
+    for (int i = 0; i < ABL_EXTRA_VALU; i += 4) {
+        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d0));
+        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d1));
+        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d2));
+        asm volatile("v_fma_f32 %0, %0, %0, %0" : "+v"(d3));
+    }
+#endif
+#ifdef ABL_EXTRA_MFMA
+    bf16x8 a = __builtin_bit_cast(bf16x8, f32x4{d0, d1, d2, d3});
+#pragma unroll
+    for (int i = 0; i < ABL_EXTRA_MFMA; ++i) dm = mfma_bf(a, a, dm);
+#endif
+}
 // ------------------------------------------------------------------------------------- kernels
 #ifndef NOGRAD_WAVES
 #define NOGRAD_WAVES 2      // measured: 3 waves per SIMD (168 registers, ~35 spilled) is 7% slower on the Stage-2 step
@@ -994,18 +1029,24 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__r
     float acc = 0.f;
     // the tile's input is loaded one tile ahead (one value per lane): no HBM latency in front of the MFMAs
     const int64_t stride = (int64_t)gridDim.x * WAVES;
+    // (no branch around the load: the index is clamped and the value selected afterwards.  With the load inside
+    // a conditional block the compiler loses count of the loads in flight across the loop edge and waits for
+    // all of them, the one just issued for the next tile included, in front of the first MFMA of every tile.)
+    // The loaded value is not touched before the next iteration either: an instruction that consumes it here
+    // (a select, a product) would bring the wait for the load to this point, and the latency would be exposed.
+    const float *src = g < 2 ? x + g : cond + (g - 2);
     auto fetch = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
-        return (tile < ntiles && n < N) ? (g < 2 ? x[2 * n + g] : cond[2 * n + g - 2]) : 0.f;
+        return src[2 * (n < N ? n : 0)];            // n >= N past the last tile as well
     };
-    float in_next = fetch((int64_t)blockIdx.x * WAVES + wave);
+    float raw_next = fetch((int64_t)blockIdx.x * WAVES + wave);
     FrontOps front;
     load_ops(front, lds, lane);
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
         const int64_t n = tile * 16 + j;
         const bool valid = n < N;
-        const float in = in_next;
-        in_next = fetch(tile + stride);
+        const float in = valid ? raw_next : 0.f;
+        raw_next = fetch(tile + stride);
         Acts a;
         Fc3Ops o3;
         forward_front(a, lds, lane, in, slope, front, [&] { load_ops(o3, lds, lane); });
@@ -1062,6 +1103,10 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
     }
     const f32x4 w4 = quad(lds, Q_W4, lane);
     float ssum = 0.f;
+#if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
+    float abl0 = slope, abl1 = slope + 1.f, abl2 = slope + 2.f, abl3 = slope + 3.f;
+    f32x4 ablm = {0.f, 0.f, 0.f, 0.f};
+#endif
 #if defined(ABL_TIMING) || defined(ABL_CLOCK)
     // experiment: shader-clock cycles and 100 MHz ticks between here and the end of the wave's loop
     const unsigned long long clk0 = __builtin_readcyclecounter(), real0 = __builtin_amdgcn_s_memrealtime();
@@ -1072,13 +1117,19 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
 #endif
     const int64_t ntiles = (N + 15) >> 4;
     // the tile's input (and upstream gradient) is loaded one tile ahead
+    // (branch-free: clamped index, value selected afterwards -- a load inside a conditional block makes the
+    // compiler wait for every load in flight, the next tile's included, in front of the tile's first MFMA)
+    const float *src = g < 2 ? x + g : cond + (g - 2);
+    const float *gsrc = gscore ? gscore : x;        // no upstream vector: any readable address, the value is not used
+    // The loaded values are not touched before the next iteration either: an instruction that consumes one
+    // here (a select, a product) would bring the wait for the load to this point and expose its latency.
     auto fetch_in = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
-        return (tile < ntiles && n < N) ? (g < 2 ? x[2 * n + g] : cond[2 * n + g - 2]) : 0.f;
+        return src[2 * (n < N ? n : 0)];            // n >= N past the last tile as well
     };
     auto fetch_gs = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
-        return (tile < ntiles && n < N) ? (gscore ? gscore[n] : gconst) : 0.f;
+        return gsrc[(n < N && gscore) ? n : 0];
     };
     FrontOps front;
     load_ops(front, lds, lane);
@@ -1090,7 +1141,7 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
     while (tile < ntiles) {
         const int64_t n = tile * 16 + j;
         const bool valid = n < N;
-        const float in = in_next, gs = gs_next;
+        const float in = valid ? in_next : 0.f, gs = valid ? (gscore ? gs_next : gconst) : 0.f;
         tq.advance(lane);
         tile = tq.tile();
         in_next = fetch_in(tile);
@@ -1257,7 +1308,13 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
             STAMP(3)
         }
 #endif
+#if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
+        abl_extra(abl0, abl1, abl2, abl3, ablm);
+#endif
     }
+#if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
+    if (abl0 + abl1 + abl2 + abl3 + ablm[0] == 1.2345f) ssum += 1.f;
+#endif
     if (WGRAD) {
         P1R p1r;
         read_p1(p1r, ad);
@@ -1322,38 +1379,41 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
     const int64_t ntiles = (N + 15) >> 4;
     const unsigned tpr = ROW1 ? 1u : (unsigned)(L >> 4);      // tiles per row
     // the tile's input is loaded one tile ahead
+    // branch-free (clamped indices, values selected afterwards; see k_critic_bwd_mfma): lane groups 2, 3 load their
+    // condition component twice and an interpolation coefficient they do not use
+    // The loaded values are carried to the next iteration untouched (an instruction consuming them here would
+    // bring the wait for the loads to this point).
+    const float *src_a = g < 2 ? real + g : cond + (g - 2), *src_b = g < 2 ? fake + g : cond + (g - 2);
+    struct Raw { float al, a, b; };
     auto fetch = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
-        float in = 0.f;
-#ifdef ABL_GPA_NOLOAD      // experiment: no global loads in the loop
-        if (tile < ntiles) return 0.01f * (float)lane + 0.1f * (float)(tile & 7);
-#endif
-        if (tile < ntiles && n < N) {
-            if (g < 2) {
-                // rows of L samples are whole tiles (L % 16 == 0, checked by the launcher): the row of a tile is one
-                // 32-bit division of wave-uniform values, not a 64-bit division per lane
-                const float al = alpha[ROW1 ? n : (int64_t)((unsigned)tile / tpr)];
-                in = al * real[2 * n + g] + (1.f - al) * fake[2 * n + g];
-            } else {
-                in = cond[2 * n + g - 2];
-            }
-        }
-        return in;
+        const int64_t m = n < N ? n : 0;            // n >= N past the last tile as well
+        // rows of L samples are whole tiles (L % 16 == 0, checked by the launcher): the row of a tile is one
+        // 32-bit division of wave-uniform values, not a 64-bit division per lane
+        Raw r;
+        r.al = alpha[ROW1 ? m : (int64_t)((unsigned)(tile < ntiles ? tile : 0) / tpr)];
+        r.a = src_a[2 * m];
+        r.b = src_b[2 * m];
+        return r;
     };
     FrontOps front;
     load_ops(front, lds, lane);
+#if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
+    float abl0 = slope, abl1 = slope + 1.f, abl2 = slope + 2.f, abl3 = slope + 3.f;
+    f32x4 ablm = {0.f, 0.f, 0.f, 0.f};
+#endif
     TileQueue tq;
     tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES);
     int64_t tile_next = tq.tile();
-    float in_next = fetch(tile_next);
+    Raw raw_next = fetch(tile_next);
     while (tile_next < ntiles) {
         const int64_t tile = tile_next;
         const int64_t n = tile * 16 + j;
         const bool valid = n < N;
-        const float in = in_next;
+        const float in = valid ? (g < 2 ? raw_next.al * raw_next.a + (1.f - raw_next.al) * raw_next.b : raw_next.a) : 0.f;
         tq.advance(lane);
         tile_next = tq.tile();
-        in_next = fetch(tile_next);
+        raw_next = fetch(tile_next);
         Acts a;
         Fc3Ops o3;
         TopOps top;
@@ -1382,7 +1442,13 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
             float sq = sum_over_j1(g0 * g0 + g1 * g1);
             if (lane == 0) tile_sq[tile] = sq;
         }
+#if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
+        abl_extra(abl0, abl1, abl2, abl3, ablm);
+#endif
     }
+#if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
+    if (abl0 + abl1 + abl2 + abl3 + ablm[0] == 1.2345f) tile_sq[0] = 0.f;
+#endif
 }
 
 // pass B (rows of L samples): per-row norm, coefficient and penalty term; one wave per row
@@ -1442,20 +1508,16 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
     const int64_t ntiles = (N + 15) >> 4;
     const unsigned tpr = ROW1 ? 1u : (unsigned)(L >> 4);      // tiles per row
     // the tile's mask word, input gradient and row coefficient are loaded one tile ahead
+    // (branch-free, clamped indices, and carried to the next iteration untouched: see k_critic_bwd_mfma)
     unsigned bits_next = 0u;
-    float2 gh_next = make_float2(0.f, 0.f);
+    float2 gv_next = make_float2(0.f, 0.f);
+    float c_next = 0.f;
     auto fetch = [&](int64_t tile) {
         const int64_t n = tile * 16 + j;
-        bits_next = 0u;
-        gh_next = make_float2(0.f, 0.f);
-        if (tile < ntiles) {
-            bits_next = maskw[tile * 64 + lane];
-            if (n < N) {
-                const float2 gv = gin[n];
-                const float c = rowc[ROW1 ? n : (int64_t)((unsigned)tile / tpr)];      // whole tiles per row, as in pass A
-                gh_next = make_float2(c * gv.x, c * gv.y);
-            }
-        }
+        const int64_t tc = tile < ntiles ? tile : 0, m = n < N ? n : 0;
+        bits_next = maskw[tc * 64 + lane];
+        gv_next = gin[m];
+        c_next = rowc[ROW1 ? m : (int64_t)((unsigned)tc / tpr)];      // whole tiles per row, as in pass A
     };
     TileQueue tq;
     tq.init(queue, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES);
@@ -1463,7 +1525,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
     fetch(tile);
     while (tile < ntiles) {
         const unsigned bits = bits_next;
-        const float gh0 = gh_next.x, gh1 = gh_next.y;
+        const bool valid = tile * 16 + j < N;
+        const float gh0 = valid ? c_next * gv_next.x : 0.f, gh1 = valid ? c_next * gv_next.y : 0.f;
         tq.advance(lane);
         tile = tq.tile();
         fetch(tile);
