@@ -188,11 +188,15 @@ class SpectralLoss(nn.Module):
             return total, {"l1": l1, "evm": evm_loss, "acpr": acpr_loss}
         return total
 
-    def compute_metrics(self, predicted: torch.Tensor, target: torch.Tensor) -> Dict[str, float]:
+    def metrics_tensor(self, predicted: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        """[evm_db, nmse_db, acpr_lower_db, acpr_upper_db, l1_error] as one device tensor (no host synchronisation)."""
         with torch.no_grad():
             l1, evm_db, lo_db, up_db, nmse_db = _loss_terms(predicted, target, self.sample_rate, self.channel_bw,
                                                            self.adjacent_offset)
-            vals = torch.stack([evm_db.mean(), nmse_db.mean(), lo_db.mean(), up_db.mean(), l1]).tolist()  # one sync
+            return torch.stack([evm_db.mean(), nmse_db.mean(), lo_db.mean(), up_db.mean(), l1])
+
+    def compute_metrics(self, predicted: torch.Tensor, target: torch.Tensor) -> Dict[str, float]:
+        vals = self.metrics_tensor(predicted, target).tolist()  # one sync
         m = dict(evm_db=vals[0], nmse_db=vals[1], acpr_lower_db=vals[2], acpr_upper_db=vals[3])
         m["acpr_max_db"] = max(m["acpr_lower_db"], m["acpr_upper_db"])
         m["l1_error"] = vals[4]
