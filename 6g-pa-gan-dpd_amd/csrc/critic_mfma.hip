@@ -19,9 +19,20 @@ namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+// experiment switches (timing only, results are wrong): ABL_NO_MFMA drops every matrix instruction but keeps its
+// data dependencies, ABL_NO_SPLIT leaves one instruction of the three-way split, ABL_NO_LDSOPS takes the weight
+// operands from registers instead of the LDS image
+#ifdef ABL_NO_MFMA
+DEV f32x4 mfma4(float a, float b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
+#else
 DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
 // sixteen independent 4x4 outer products: lane 4b + i of `a` times lane 4b + j of `b` -> register i of lane 4b + j
+#ifdef ABL_NO_MFMA
+DEV f32x4 mfma_blocks(float a, float b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
+#else
 DEV f32x4 mfma_blocks(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, c, 0, 0, 0); }
+#endif
 
 constexpr int WAVES = 4;
 // waves per workgroup of the weight-gradient kernels: one operand image serves all of them, so a large
@@ -264,7 +275,15 @@ DEV void load_ops(InOps &o, const float *img, int lane) {
 }
 
 #if CRITIC_BF16X3
+#ifdef ABL_NO_LDSOPS
+DEV bf16x8 bquad(const float *img, int q, int lane) {
+    f32x4 v = {(float)q, (float)lane, 1.f, 2.f};
+    asm volatile("" : "+v"(v));
+    return __builtin_bit_cast(bf16x8, v);
+}
+#else
 DEV bf16x8 bquad(const float *img, int q, int lane) { return reinterpret_cast<const bf16x8 *>(img)[q * 64 + lane]; }
+#endif
 struct B3 {            // eight values per lane, split three ways
     bf16x8 h, m, l;
 };
@@ -281,6 +300,11 @@ DEV void split_pair(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
     typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
     const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
     h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+#ifdef ABL_NO_SPLIT
+    m = h;
+    l = h;
+    return;
+#endif
     const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
     const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
     m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
@@ -299,7 +323,11 @@ DEV void split8(B3 &o, const f32x4 &x0, const f32x4 &x1) {
     o.m = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
     o.l = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
 }
+#ifdef ABL_NO_MFMA
+DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
+#else
 DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#endif
 // c + a x b to fp32 accuracy: two chains of three products each, small terms first
 DEV void mfma6(f32x4 &lo, f32x4 &hi, const B3 &a, const B3 &b) {
     PRIO_UP();
@@ -457,8 +485,12 @@ DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps
     for (int k = 0; k < 6; ++k) {
         typedef short s16x8 __attribute__((ext_vector_type(8)));
         const s16x8 w = __builtin_bit_cast(s16x8, o.t[ta[k]]);
+#ifdef ABL_NO_MFMA
+        asm volatile("" : "+v"(e0), "+v"(e1) : "v"(w), "v"(b[tb[k]]));
+#else
         e0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[0], w[1], w[2], w[3]}, b[tb[k]], e0, 0, 0, 0);
         e1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[4], w[5], w[6], w[7]}, b[tb[k]], e1, 0, 0, 0);
+#endif
     }
     PRIO_DOWN();
     FENCE();
@@ -951,29 +983,45 @@ DEV void combine_rows(float *lds, float *slab_row) {
 }
 
 // ---- tile hand-out ----------------------------------------------------------------------------------
-// Units of UNIT consecutive tiles are handed out through a device counter, first come, first served: CUs
+// Units of consecutive tiles are handed out through a device counter, first come, first served: CUs
 // run these kernels at visibly different speeds (per-wave run times of one launch spread by +-13% under
-// a fixed assignment), and the launch ends with its slowest wave.  The counter is bumped one unit ahead
-// with a hand-issued atomic (lane 0 only: the asm narrows exec itself, so no branch and no merge of
-// register values surrounds it) whose result stays in next_raw until the unit is started; the
-// compiler's own atomic sequence waits for the round trip at once.  The compiler does not count this
-// load, hence the explicit wait before the value is read (wait and read are one asm statement, and the
-// atomic takes next_raw as an in/out operand: no copy of the register between the issue and the wait).
-// queue == NULL: units in a fixed round-robin order (results then do not depend on timing).  The first
-// unit of a wave is its own index.  The loops that use this are wave-uniform (all lanes active).
+// a fixed assignment), and the launch ends with its slowest wave.  Every hand-out is an atomic on one
+// address, and those take their turn in the L2 at about 12 ns each: with units of 8 tiles, 2^17 of them per
+// launch at 2^24 samples were a floor of 1.5 ms under every kernel of this file (measured: the kernels took
+// that long with their matrix instructions removed).  So a unit is BIG tiles long over the first 7/8 of the
+// tiles and SMALL over the rest, where the grain decides how evenly the waves finish: 36,864 atomics.
+// The counter is bumped one unit ahead with a hand-issued atomic (lane 0 only: the asm narrows exec itself,
+// so no branch and no merge of register values surrounds it) whose result stays in next_raw until the unit
+// is started; the compiler's own atomic sequence waits for the round trip at once.  The compiler does not
+// count this load, hence the explicit wait before the value is read (wait and read are one asm statement,
+// and the atomic takes next_raw as an in/out operand: no copy of the register between the issue and the
+// wait).  queue == NULL: units in a fixed round-robin order (results then do not depend on timing).  The
+// first unit of a wave is its own index.  The loops that use this are wave-uniform (all lanes active).
+#ifndef TILE_UNIT_BIG
+#define TILE_UNIT_BIG 32
+#endif
+#ifndef TILE_UNIT_SMALL
+#define TILE_UNIT_SMALL 16
+#endif
 struct TileQueue {
-    static constexpr unsigned UNIT = 8;
+    static constexpr unsigned BIG = TILE_UNIT_BIG, SMALL = TILE_UNIT_SMALL;
     unsigned *queue;
-    unsigned n_waves, static_next, unit, in_unit, next_raw;
-    DEV void init(unsigned *q, unsigned first, unsigned waves) {
+    unsigned n_waves, static_next, n_big, len, in_unit, next_raw;
+    int64_t base;                                 // first tile of the current unit
+    DEV void start(unsigned u) {                  // unit u: BIG tiles each below n_big, SMALL from there on
+        len = u < n_big ? BIG : SMALL;
+        base = u < n_big ? (int64_t)u * BIG : (int64_t)n_big * BIG + (int64_t)(u - n_big) * SMALL;
+        in_unit = 0;
+    }
+    DEV void init(unsigned *q, unsigned first, unsigned waves, int64_t ntiles) {
         queue = q;
         n_waves = waves;
         static_next = first;
-        unit = first;
-        in_unit = 0;
+        n_big = (unsigned)((ntiles - (ntiles >> 3)) / BIG);
         next_raw = 0;
+        start(first);
     }
-    DEV int64_t tile() const { return (int64_t)unit * UNIT + in_unit; }
+    DEV int64_t tile() const { return base + in_unit; }
     DEV void advance(int lane) {
         if (in_unit == 1 && queue != nullptr) {
             const unsigned one = 1u;
@@ -983,14 +1031,13 @@ struct TileQueue {
                          : "v"(queue), "v"(one)
                          : "memory");
         }
-        if (++in_unit == UNIT) {
-            in_unit = 0;
+        if (++in_unit == len) {
             if (queue != nullptr) {
                 unsigned raw;   // wait and read in one statement: nothing can read the register in between
                 asm volatile("s_waitcnt vmcnt(0)\n\tv_readfirstlane_b32 %0, %1" : "=s"(raw) : "v"(next_raw) : "memory");
-                unit = n_waves + raw;
+                start(n_waves + raw);
             } else {
-                unit = n_waves + static_next;
+                start(n_waves + static_next);
                 static_next += n_waves;
             }
         }
@@ -1135,7 +1182,7 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
     load_ops(front, lds, lane);
     TileQueue tq;
     constexpr int NW = WGRAD ? WG_WAVES : WAVES;
-    tq.init(queue, blockIdx.x * NW + wave, gridDim.x * NW);
+    tq.init(queue, blockIdx.x * NW + wave, gridDim.x * NW, ntiles);
     int64_t tile = tq.tile();
     float in_next = fetch_in(tile), gs_next = fetch_gs(tile);
     while (tile < ntiles) {
@@ -1403,7 +1450,7 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
     f32x4 ablm = {0.f, 0.f, 0.f, 0.f};
 #endif
     TileQueue tq;
-    tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES);
+    tq.init(queue, blockIdx.x * WAVES + wave, gridDim.x * WAVES, ntiles);
     int64_t tile_next = tq.tile();
     Raw raw_next = fetch(tile_next);
     while (tile_next < ntiles) {
@@ -1520,7 +1567,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         c_next = rowc[ROW1 ? m : (int64_t)((unsigned)tc / tpr)];      // whole tiles per row, as in pass A
     };
     TileQueue tq;
-    tq.init(queue, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES);
+    tq.init(queue, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, ntiles);
     int64_t tile = tq.tile();
     fetch(tile);
     while (tile < ntiles) {
