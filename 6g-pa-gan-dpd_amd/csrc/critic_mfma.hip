@@ -1180,6 +1180,9 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
     };
     FrontOps front;
     load_ops(front, lds, lane);
+#ifdef ABL_PHASE_SHIFT     // experiment: the second wave of every SIMD starts a fraction of a tile late
+    if (WGRAD && wave >= WG_WAVES / 2) __builtin_amdgcn_s_sleep(ABL_PHASE_SHIFT);
+#endif
     TileQueue tq;
     constexpr int NW = WGRAD ? WG_WAVES : WAVES;
     tq.init(queue, blockIdx.x * NW + wave, gridDim.x * NW, ntiles);

@@ -956,7 +956,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // Units of UNIT consecutive chunks are handed out through a device counter (first come, first
     // served): waves on faster or earlier-started CUs take more units, none idles at the end.  The
     // counter is read one unit ahead, so its latency stays hidden.  n_chunks < 2^31 (checked on the host).
-    constexpr unsigned UNIT = 4;
+#ifndef GEN_BWD_UNIT
+#define GEN_BWD_UNIT 4
+#endif
+    constexpr unsigned UNIT = GEN_BWD_UNIT;
     const unsigned n_waves = gridDim.x * WAVES, cpr32 = (unsigned)cpr, n_chunks32 = (unsigned)n_chunks;
     // The counter is bumped with a hand-issued atomic whose result stays in a vector register until the
     // unit is started (one unit later): the compiler's own atomic sequence waits for the round trip at

@@ -36,6 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_PEAK_TFLOPS = 157.3      # MI355X fp32 vector == fp32 MFMA dense peak (256 CU x 4 SIMD x 64 flop/cycle x 2.4 GHz)
+BF16_PEAK_TFLOPS = 2500.0     # dense bf16 MFMA peak (v_mfma_f32_16x16x32_bf16: 16,384 flop per 16 cycles and SIMD)
 HBM_PEAK_GBS = 8000.0
 CLOCK_HZ = 2.4e9
 N_SIMD = 1024
@@ -271,6 +272,7 @@ def run_stage2(ctx, args, steps, warmup):
     kflop = 2.0 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC) * n
     tiles_per_simd = n / 16.0 / N_SIMD
     issue_s = tiles_per_simd * CRITIC_BWD_MFMA_CYCLES / CLOCK_HZ
+    bf16_flop = (n / 16.0) * (84 * 2 * 16 * 16 * 32 + 12 * 2 * 16 * 16 * 16)
     roof = {"bound": "mfma",
             "kernel": "k_critic_bwd_mfma<true,false>: critic forward + backward with weight gradients in one pass "
                       "(10 of the step's launches); fp32 MFMA for FC1 and the first-layer weight gradient, hidden-layer "
@@ -278,11 +280,16 @@ def run_stage2(ctx, args, steps, warmup):
             # algorithmic flops of the pass (2 x (2,832 + 5,408) MAC per sample) over the measured kernel time, against the
             # fp32 peak: the arithmetic is fp32-accurate, whichever matrix pipe carries it
             "achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kflop / k / 1e12 / FP32_PEAK_TFLOPS,
-            "frac_definition": "algorithmic fp32 flops per launch / kernel time / fp32 MFMA peak (an fp32-equivalent rate: "
-                               "part of the products runs on the bf16 pipe, see mfma_issue_frac for the utilisation)",
+            "frac_definition": "algorithmic fp32 flops per launch / kernel time / fp32 MFMA peak (an fp32-equivalent rate, which "
+                               "can pass 1: 96 of the 116 MFMAs of a tile run on the bf16 pipe as split products of fp32 accuracy; "
+                               "mfma_issue_frac and bf16_executed are the utilisations)",
             # utilisation: the time the kernel's MFMAs need at their own peak issue rates (fp32 157.3 TFLOP/s, bf16 2.5 PFLOP/s
             # dense) over the measured time
             "mfma_issue_frac": issue_s / k, "mfma_issue_ms": issue_s * 1e3, "kernel_ms": k * 1e3,
+            # the bf16 side by itself: flops the kernel's bf16 MFMAs execute (84 16x16x32 and 12 16x16x16 per tile of 16
+            # samples: six products per fp32-accurate product) over the kernel time, against the dense bf16 peak
+            "bf16_executed": {"achieved": bf16_flop / k / 1e12, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                              "frac": bf16_flop / k / 1e12 / BF16_PEAK_TFLOPS},
             "flop_per_sample": 2 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC),
             "traffic": pmc_bytes("k_critic_bwd_mfma<true,false>") if default_shape(ctx) else None,
             "step_fp32_equivalent_tflops": 2.0 * mac * n / t / 1e12, "step_flop_per_sample": 2 * mac,
