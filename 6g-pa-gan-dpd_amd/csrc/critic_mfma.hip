@@ -466,10 +466,22 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
 // back-propagation of an upstream vector through the three hidden layers, in two steps:
 //   top[r] (16 values on neurons 4g + r of layer 3, already masked) -> d2[2] (layer 2, masked) -> d1[4] (layer 1, masked)
 // The first step contracts over 16 neurons: v_mfma_f32_16x16x16_bf16, whose k = 4g + e is what a lane holds.
-template <class Pre, class Keep = NoKeep>
-DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps &o, Pre pre, Keep keep = Keep()) {
+// The MFMAs of one wave and the VALU instructions of another wave of the same SIMD do not overlap on this part
+// (scratch/ubench/cross_wave_overlap.hip: their times add up), so a burst of MFMAs hides nothing unless the
+// wave itself has independent VALU work in the same stretch of code.  Hence the order here: the first 16-row
+// tile's chain of six MFMAs, then the second tile's six with the masking and the three-way split of the first
+// tile's result beside them; the split of the second tile's result sits beside over() -- the caller's next
+// MFMAs that do not depend on it (the FC3 weight gradient) -- and sd2 hands the terms on to chain_bottom.
+struct NoOp {
+    DEV void operator()() const {}
+};
+template <class Pre, class Keep = NoKeep, class Over = NoOp>
+DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], B3 &sd2, const TopOps &o, Pre pre, Keep keep = Keep(),
+                   Over over = Over()) {
     pre();
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
     unsigned bh[2], bm[2], bl[2];
     split_pair(top[0], top[1], bh[0], bm[0], bl[0]);
     split_pair(top[2], top[3], bh[1], bm[1], bl[1]);
@@ -480,31 +492,46 @@ DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], const TopOps
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
     // products in the order mm, lh, hl, mh, hm, hh (term of the weights, term of the activations)
     const int ta[6] = {1, 2, 0, 1, 0, 0}, tb[6] = {1, 0, 2, 0, 1, 0};
-    PRIO_UP();
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
-        typedef short s16x8 __attribute__((ext_vector_type(8)));
         const s16x8 w = __builtin_bit_cast(s16x8, o.t[ta[k]]);
 #ifdef ABL_NO_MFMA
-        asm volatile("" : "+v"(e0), "+v"(e1) : "v"(w), "v"(b[tb[k]]));
+        asm volatile("" : "+v"(e0) : "v"(w), "v"(b[tb[k]]));
 #else
         e0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[0], w[1], w[2], w[3]}, b[tb[k]], e0, 0, 0, 0);
+#endif
+    }
+    FENCE();
+    unsigned h[4], m[4], l[4];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        const s16x8 w = __builtin_bit_cast(s16x8, o.t[ta[k]]);
+#ifdef ABL_NO_MFMA
+        asm volatile("" : "+v"(e1) : "v"(w), "v"(b[tb[k]]));
+#else
         e1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[4], w[5], w[6], w[7]}, b[tb[k]], e1, 0, 0, 0);
 #endif
     }
-    PRIO_DOWN();
-    FENCE();
     d2[0] = e0 * m2[0];
+    split_pair(d2[0][0], d2[0][1], h[0], m[0], l[0]);
+    split_pair(d2[0][2], d2[0][3], h[1], m[1], l[1]);
+    FENCE();
+    over();
     d2[1] = e1 * m2[1];
+    split_pair(d2[1][0], d2[1][1], h[2], m[2], l[2]);
+    split_pair(d2[1][2], d2[1][3], h[3], m[3], l[3]);
+    sd2.h = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
+    sd2.m = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
+    sd2.l = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
 }
-// pre() runs before the second half
+// b: the three-way split of d2 (from chain_top).  pre() runs before the second half, whose MFMAs have the masking
+// of the first half's result beside them.
 template <class Pre, class Keep = NoKeep>
-DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f32x4 (&m1)[4], f32x4 (&d1)[4], const BotOps &o,
-                      Pre pre, Keep keep = Keep()) {
-    B3 w2[2], b;
+DEV void chain_bottom(const float *img, int lane, const f32x4 (&)[2], const B3 &b, const f32x4 (&m1)[4], f32x4 (&d1)[4],
+                      const BotOps &o, Pre pre, Keep keep = Keep()) {
+    B3 w2[2];
     load_b3(w2[0], img, QB_A2T + 6, lane);
     load_b3(w2[1], img, QB_A2T + 9, lane);
-    split8(b, d2[0], d2[1]);
     keep(b);
     FENCE();
     f32x4 f[4], flo[4];
@@ -520,11 +547,21 @@ DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f3
     FENCE();
     mfma6(flo[2], f[2], w2[0], b);
     mfma6(flo[3], f[3], w2[1], b);
+    d1[0] = (f[0] + flo[0]) * m1[0];
+    d1[1] = (f[1] + flo[1]) * m1[1];
     FENCE();
-#pragma unroll
-    for (int t = 0; t < 4; ++t) d1[t] = (f[t] + flo[t]) * m1[t];
+    d1[2] = (f[2] + flo[2]) * m1[2];
+    d1[3] = (f[3] + flo[3]) * m1[3];
 }
 #else
+struct B3 {};          // (the split terms exist only in the bf16 build)
+struct NoKeep {
+    DEV void operator()(int, const B3 &) const {}
+    DEV void operator()(const B3 &) const {}
+};
+struct NoOp {
+    DEV void operator()() const {}
+};
 struct FrontOps {      // FC1 weights and accumulator start (b1), FC2 accumulator start (b2), first FC2 weight pair
     f32x4 a1, b1[4], b2[2], w0, w1;
 };
@@ -671,6 +708,17 @@ DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const f3
     for (int t = 0; t < 4; ++t) d1[t] = f[t] * m1[t];
 }
 
+// the call shape of the bf16 build (split terms handed from chain_top to chain_bottom): nothing to hand over here
+template <class Pre, class Keep = NoKeep, class Over = NoOp>
+DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], B3 &, const TopOps &o, Pre pre, Keep = Keep(), Over over = Over()) {
+    chain_top(top, m2, d2, o, pre);
+    over();
+}
+template <class Pre, class Keep = NoKeep>
+DEV void chain_bottom(const float *img, int lane, const f32x4 (&d2)[2], const B3 &, const f32x4 (&m1)[4], f32x4 (&d1)[4],
+                      const BotOps &o, Pre pre, Keep = Keep()) {
+    chain_bottom(img, lane, d2, m1, d1, o, pre);
+}
 #endif
 
 // (W1[:, 0:2])^T d1 -> the two input-gradient components, in every lane of sample j.  Two of sixteen
@@ -1237,7 +1285,8 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
         const f32x4 (&m2)[2] = a.m2;
         const f32x4 gz3 = w4 * gs * a.m3;
         f32x4 gz2[2], gz1[4];
-        chain_top(gz3, m2, gz2, top, [&] { load_ops(bot, lds, lane); },
+        B3 sgz2;
+        chain_top(gz3, m2, gz2, sgz2, top, [&] { load_ops(bot, lds, lane); },
                   [&](const unsigned (&bh)[2], const unsigned (&bm)[2], const unsigned (&bl)[2]) {
                       if (WGRAD) {
                           park_single(ad, S_D3, bh, bm, bl);
@@ -1246,18 +1295,22 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
                           read_single_op(d3r, ad, S_D3);
                           __builtin_amdgcn_wave_barrier();
                       }
+                  },
+                  [&] {      // p3, beside the split of the second half of gz2
+                      if (WGRAD) {
+                          ac.p3[0] = mfma_bf(h2l[0].hl, d3r.lh, ac.p3[0]);
+                          ac.p3[1] = mfma_bf(h2l[1].hl, d3r.lh, ac.p3[1]);
+                          ac.p3[0] = mfma_bf(h2l[0].hm, d3r.mh, ac.p3[0]);
+                          ac.p3[1] = mfma_bf(h2l[1].hm, d3r.mh, ac.p3[1]);
+                          ac.p3[0] = mfma_bf(h2l[0].hm, d3r.hm, ac.p3[0]);
+                          ac.p3[1] = mfma_bf(h2l[1].hm, d3r.hm, ac.p3[1]);
+                      }
                   });
         if (WGRAD) {
-            ac.p3[0] = mfma_bf(h2l[0].hl, d3r.lh, ac.p3[0]);
-            ac.p3[1] = mfma_bf(h2l[1].hl, d3r.lh, ac.p3[1]);
-            ac.p3[0] = mfma_bf(h2l[0].hm, d3r.mh, ac.p3[0]);
-            ac.p3[1] = mfma_bf(h2l[1].hm, d3r.mh, ac.p3[1]);
-            ac.p3[0] = mfma_bf(h2l[0].hm, d3r.hm, ac.p3[0]);
-            ac.p3[1] = mfma_bf(h2l[1].hm, d3r.hm, ac.p3[1]);
             db2[0] += gz2[0];
             db2[1] += gz2[1];
         }
-        chain_bottom(lds, lane, gz2, m1, gz1, bot, [&] {
+        chain_bottom(lds, lane, gz2, sgz2, m1, gz1, bot, [&] {
             if (WGRAD) {
                 read_pair_op(d2r[0], ad, S_D2, 0);
                 read_pair_op(d2r[1], ad, S_D2, 1);
@@ -1322,7 +1375,8 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
         // of the chain, whose MFMAs cover the LDS round trip: p3 (h2 x gz3) around the top of the chain,
         // p2 (h1 x gz2) around its bottom; only p1 (gz1 x input) follows its own park directly.
         if (WGRAD) park_p3(ad, a.h2, gz3);
-        chain_top(gz3, m2, gz2, top, [&] {
+        B3 sgz2;
+        chain_top(gz3, m2, gz2, sgz2, top, [&] {
             load_ops(bot, lds, lane);
             if (WGRAD) read_p3(p3r, ad);
         });
@@ -1330,7 +1384,7 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
             mfma_p3(ac, p3r);
             park_p2(ad, a.h1, gz2);
         }
-        chain_bottom(lds, lane, gz2, m1, gz1, bot, [&] {
+        chain_bottom(lds, lane, gz2, sgz2, m1, gz1, bot, [&] {
             if (WGRAD) read_p2(p2r, ad);
             if (DX) load_ops(ino, lds, lane);
         });
@@ -1476,8 +1530,9 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         const unsigned bits = a.bits;
         const f32x4 v3 = w4 * a.m3;
         f32x4 v2[2], v1[4];
-        chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); });
-        chain_bottom(lds, lane, v2, m1, v1, bot, [&] { load_ops(ino, lds, lane); });
+        B3 sv2;
+        chain_top(v3, m2, v2, sv2, top, [&] { load_ops(bot, lds, lane); });
+        chain_bottom(lds, lane, v2, sv2, m1, v1, bot, [&] { load_ops(ino, lds, lane); });
         load_ops(front, lds, lane);          // next tile
         FENCE();
         float g0, g1;
@@ -1633,21 +1688,24 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
                                       [&](const B3 &b) { park_b3(ad, S_H2, b); });      // after read_p1: inside the p1 tile
         FENCE();
         dw4 += dv3 * m3;
-        chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); },
+        B3 sv2;
+        chain_top(v3, m2, v2, sv2, top, [&] { load_ops(bot, lds, lane); },
                   [&](const unsigned (&bh)[2], const unsigned (&bm)[2], const unsigned (&bl)[2]) {
                       park_single(ad, S_D3, bh, bm, bl);
                       read_pair_op(du2l[0], ad, S_H2, 0);
                       read_pair_op(du2l[1], ad, S_H2, 1);
                       read_single_op(v3r, ad, S_D3);
                       __builtin_amdgcn_wave_barrier();
+                  },
+                  [&] {      // p3, beside the split of the second half of v2
+                      ac.p3[0] = mfma_bf(du2l[0].hl, v3r.lh, ac.p3[0]);
+                      ac.p3[1] = mfma_bf(du2l[1].hl, v3r.lh, ac.p3[1]);
+                      ac.p3[0] = mfma_bf(du2l[0].hm, v3r.mh, ac.p3[0]);
+                      ac.p3[1] = mfma_bf(du2l[1].hm, v3r.mh, ac.p3[1]);
+                      ac.p3[0] = mfma_bf(du2l[0].hm, v3r.hm, ac.p3[0]);
+                      ac.p3[1] = mfma_bf(du2l[1].hm, v3r.hm, ac.p3[1]);
                   });
-        ac.p3[0] = mfma_bf(du2l[0].hl, v3r.lh, ac.p3[0]);
-        ac.p3[1] = mfma_bf(du2l[1].hl, v3r.lh, ac.p3[1]);
-        ac.p3[0] = mfma_bf(du2l[0].hm, v3r.mh, ac.p3[0]);
-        ac.p3[1] = mfma_bf(du2l[1].hm, v3r.mh, ac.p3[1]);
-        ac.p3[0] = mfma_bf(du2l[0].hm, v3r.hm, ac.p3[0]);
-        ac.p3[1] = mfma_bf(du2l[1].hm, v3r.hm, ac.p3[1]);
-        chain_bottom(lds, lane, v2, m1, v1, bot, [&] {
+        chain_bottom(lds, lane, v2, sv2, m1, v1, bot, [&] {
             read_pair_op(v2r[0], ad, S_D2, 0);
             read_pair_op(v2r[1], ad, S_D2, 1);
             read_pair_op(du1l[0], ad, S_H1, 0);
@@ -1704,9 +1762,10 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         FENCE();
         dw4 += dv3 * m3;
         mfma_p3(ac, p3r);
-        chain_top(v3, m2, v2, top, [&] { load_ops(bot, lds, lane); });
+        B3 sv2;
+        chain_top(v3, m2, v2, sv2, top, [&] { load_ops(bot, lds, lane); });
         park_p2(ad, du1, v2);
-        chain_bottom(lds, lane, v2, m1, v1, bot, [&] { read_p2(p2r, ad); });
+        chain_bottom(lds, lane, v2, sv2, m1, v1, bot, [&] { read_p2(p2r, ad); });
         load_ops(front, lds, lane);           // next tile
         FENCE();
         mfma_p2(ac, p2r);
