@@ -1013,9 +1013,13 @@ DEV f32x4 sum_over_j(f32x4 v) {
         for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], off);
     return v;
 }
+// sum over the 16 lanes of a lane group, left in every lane: four adds whose second operand is the lane's row
+// rotated by 8, 4, 2, 1 (DPP row_ror; no trip through the LDS crossbar, which a shuffle would take)
 DEV float sum_over_j1(float v) {
-#pragma unroll
-    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
     return v;
 }
 
