@@ -556,8 +556,18 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
             // LeakyReLU(zmax) = zmax >= 0, LeakyReLU(zmin) = slope * zmin <= 0 (one rounding, as in lrelu4)
             amax = fmaxf(zmax, fabsf(slope * zmin));
         }
+        // one atomic per workgroup: atomics on one address take their turn in the L2 (about 12 ns each), and the
+        // waves of a launch all arrive here at about the same time
         amax = wave_max(amax);
-        if (lane == 0) atomic_max_nonneg(absmax + DEPTH, amax);
+        __shared__ float wg_max[WAVES];
+        if (lane == 0) wg_max[wave] = amax;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float m = wg_max[0];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) m = fmaxf(m, wg_max[w]);
+            atomic_max_nonneg(absmax + DEPTH, m);
+        }
     }
 }
 
