@@ -31,6 +31,7 @@ static int g_critic_impl = 0;
 extern int g_gen_deterministic;
 extern int g_critic_deterministic;
 extern int g_chain_carry;
+extern int g_gp_fused;
 static bool critic_use_mfma(int64_t N) { return g_critic_impl == 2 || (g_critic_impl == 0 && N >= 1024); }
 
 extern "C" int dpd_set_option(const char *name, int value) {
@@ -49,6 +50,10 @@ extern "C" int dpd_set_option(const char *name, int value) {
     }
     if (__builtin_strcmp(name, "chain_carry") == 0 && value >= 0 && value <= 2) {
         g_chain_carry = value;
+        return DPD_OK;
+    }
+    if (__builtin_strcmp(name, "gp_fused") == 0 && (value == 0 || value == 1)) {
+        g_gp_fused = value;
         return DPD_OK;
     }
     dpd_set_error("set_option: unknown option %s or bad value %d", name, value);

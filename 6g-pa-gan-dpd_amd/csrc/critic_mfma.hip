@@ -1058,9 +1058,10 @@ DEV void combine_rows(float *lds, float *slab_row) {
 struct TileQueue {
     static constexpr unsigned BIG = TILE_UNIT_BIG, SMALL = TILE_UNIT_SMALL;
     unsigned *queue;
-    unsigned n_waves, static_next, n_big, len, in_unit, next_raw;
+    unsigned n_waves, static_next, n_big, len, in_unit, next_raw, unit;
     int64_t base;                                 // first tile of the current unit
     DEV void start(unsigned u) {                  // unit u: BIG tiles each below n_big, SMALL from there on
+        unit = u;
         len = u < n_big ? BIG : SMALL;
         base = u < n_big ? (int64_t)u * BIG : (int64_t)n_big * BIG + (int64_t)(u - n_big) * SMALL;
         in_unit = 0;
@@ -1796,6 +1797,224 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
     combine_rows(lds, slab + (int64_t)blockIdx.x * C_SLAB);
 }
 
+#if CRITIC_OUTER_BF16
+// ---- gradient penalty in one pass over the samples ------------------------------------------------------------
+// The weight gradient of the penalty is linear in the row coefficient c_b = 2(|g_b| - 1) / (|g_b| B):
+//   d gp / dW = sum over rows b of c_b * G_b,   G_b = sum over the samples of row b of (terms in g, not in c_b),
+// so the reverse chain of pass C can run with the unscaled input gradient g in the same kernel that computes g, and
+// the coefficient is applied afterwards to partial sums that do not cross a row: every hand-out unit (32 or 16
+// tiles; rows are a multiple of 32 tiles here, so a unit lies inside one row) writes its own partial weight
+// gradient, in accumulator layout, and k_gp_combine forms sum_u c_row(u) * partial[u].  Against the three-pass form
+// this saves the second evaluation of the v-chain (36 MFMAs and its splits), packing and unpacking the mask
+// bits, the mask words and g in HBM, and a launch: 150 instead of 186 MFMAs, about 600 instead of 770 VALU
+// instructions per tile.
+constexpr int GP_PART = 48;          // floats per lane of a partial: W1 gradient 4, W2 gradient 32, W3 gradient 8, W4 gradient 4
+__global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(const float *__restrict__ real, const float *__restrict__ fake,
+                                                              const float *__restrict__ cond, const float *__restrict__ alpha,
+                                                              int64_t N, int64_t L, const float *__restrict__ wb, float slope,
+                                                              float *__restrict__ partial, float *__restrict__ tile_sq,
+                                                              unsigned *__restrict__ queue) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // LDS_WORDS
+    build_image(lds, wb);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + wave * WAVE_WORDS);
+    Addr ad;
+    Accum ac;
+    make_addr(ad, wbuf, j, g);
+    zero_accum(ac);
+    {
+        float *cst = lds + IMG_WORDS + wave * WAVE_WORDS + CONST_W;
+        for (int k = lane; k < 256; k += 64) cst[k] = 0.f;     // columns 2, 3 of the g tile stay 0
+        float *left = lds + IMG_WORDS + wave * WAVE_WORDS + LEFT_W;
+        for (int k = lane; k < 16 * P64; k += 64) left[k] = 0.f;
+        __builtin_amdgcn_wave_barrier();
+    }
+    f32x4 dw4 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4 w4 = quad(lds, Q_W4, lane);
+    const int64_t ntiles = (N + 15) >> 4;
+    const unsigned tpr = (unsigned)(L >> 4);      // tiles per row
+    // inputs one tile ahead: branch-free, carried untouched (see k_critic_bwd_mfma)
+    const float *src_a = g < 2 ? real + g : cond + (g - 2), *src_b = g < 2 ? fake + g : cond + (g - 2);
+    struct Raw { float al, a, b; };
+    auto fetch = [&](int64_t tile) {
+        const int64_t n = tile * 16 + j;
+        const int64_t m = n < N ? n : 0;
+        Raw r;
+        r.al = alpha[(int64_t)((unsigned)(tile < ntiles ? tile : 0) / tpr)];
+        r.a = src_a[2 * m];
+        r.b = src_b[2 * m];
+        return r;
+    };
+    FrontOps front;
+    load_ops(front, lds, lane);
+    TileQueue tq;
+    tq.init(queue, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, ntiles);
+    int64_t tile_next = tq.tile();
+    Raw raw_next = fetch(tile_next);
+    while (tile_next < ntiles) {
+        const int64_t tile = tile_next;
+        const int64_t n = tile * 16 + j;
+        const bool valid = n < N;
+        const float in = valid ? (g < 2 ? raw_next.al * raw_next.a + (1.f - raw_next.al) * raw_next.b : raw_next.a) : 0.f;
+        const unsigned unit_now = tq.unit;
+        const bool unit_ends = tq.in_unit + 1 == tq.len;      // wave-uniform
+        tq.advance(lane);
+        tile_next = tq.tile();
+        raw_next = fetch(tile_next);
+        Acts a;
+        Fc3Ops o3;
+        TopOps top;
+        BotOps bot;
+        InOps ino;
+        P1R p1r;
+        // forward at the interpolate; the previous tile's v1 x g (parked a whole tile ago) beside it
+        forward_front(a, lds, lane, in, slope, front, [&] {
+            load_ops(o3, lds, lane);
+            read_p1(p1r, ad);
+        });
+        mfma_p1(ac, p1r);
+        forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
+        const f32x4 (&m1)[4] = a.m1;
+        const f32x4 (&m2)[2] = a.m2;
+        const f32x4 m3 = a.m3;
+        // v-chain: input gradient of the score; the terms of v3 and v2 stay parked for the outer products
+        const f32x4 v3 = w4 * m3;
+        f32x4 v2[2], v1[4];
+        B3 sv2;
+        chain_top(v3, m2, v2, sv2, top, [&] { load_ops(bot, lds, lane); },
+                  [&](const unsigned (&bh)[2], const unsigned (&bm)[2], const unsigned (&bl)[2]) { park_single(ad, S_D3, bh, bm, bl); });
+        chain_bottom(lds, lane, v2, sv2, m1, v1, bot, [&] { load_ops(ino, lds, lane); },
+                     [&](const B3 &b) { park_b3(ad, S_D2, b); });      // after read_p1: inside the p1 tile
+        float g0, g1;
+        to_input(v1, g0, g1, ino);
+        if (!valid) { g0 = 0.f; g1 = 0.f; }
+        {
+            const float sq = sum_over_j1(g0 * g0 + g1 * g1);
+            if (lane == 0) tile_sq[tile] = sq;
+        }
+        // u-chain with the unscaled g: du1 = (W1[:, 0:2] g) * D1, du2 = (W2 du1) * D2, dv3 = W3 du2
+        const float ghb = g == 0 ? g0 : (g == 1 ? g1 : 0.f);
+        f32x4 du1[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) du1[t] = mfma4(front.a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f}) * m1[t];
+        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
+        unsigned no_bits = 0u;
+        f32x4 unused_m[4];
+        OpL du2l[2], du1l[2];
+        OpR v3r, v2r[2];
+        fc2_block<false, false>(z0, z1, du1, front.w, unused_m, no_bits, lds, lane, slope, [&] {
+            load_ops(o3, lds, lane);
+            read_pair_op(v2r[0], ad, S_D2, 0);
+            read_pair_op(v2r[1], ad, S_D2, 1);
+            __builtin_amdgcn_wave_barrier();
+        }, nullptr, [&](int half, const B3 &b) { park_b3(ad, S_H1 + 3 * SLOT_B * half, b); });
+        // p2 = du1 x v2 first: the slots of v2 are then free for the terms of du2
+        read_pair_op(du1l[0], ad, S_H1, 0);
+        read_pair_op(du1l[1], ad, S_H1, 1);
+        FENCE();
+        outer3x2(ac.p2[0][0], ac.p2[0][1], du1l[0], v2r[0], v2r[1]);
+        FENCE();
+        read_pair_op(du1l[0], ad, S_H1 + 3 * SLOT_B, 0);
+        FENCE();
+        outer3x2(ac.p2[1][0], ac.p2[1][1], du1l[1], v2r[0], v2r[1]);
+        FENCE();
+        read_pair_op(du1l[1], ad, S_H1 + 3 * SLOT_B, 1);
+        FENCE();
+        outer3x2(ac.p2[2][0], ac.p2[2][1], du1l[0], v2r[0], v2r[1]);
+        FENCE();
+        outer3x2(ac.p2[3][0], ac.p2[3][1], du1l[1], v2r[0], v2r[1]);
+        __builtin_amdgcn_wave_barrier();
+        f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
+        FENCE();
+        const f32x4 dv3 = fc3_product(du2[0], du2[1], o3.w, f32x4{0.f, 0.f, 0.f, 0.f}, [&](const B3 &b) {
+            park_b3(ad, S_H2, b);                             // the slots of v2: their reads are issued
+            read_pair_op(du2l[0], ad, S_H2, 0);
+            read_pair_op(du2l[1], ad, S_H2, 1);
+            read_single_op(v3r, ad, S_D3);
+            __builtin_amdgcn_wave_barrier();
+        });
+        FENCE();
+        dw4 += dv3 * m3;
+        load_ops(front, lds, lane);           // next tile
+        // p3 = du2 x v3
+        ac.p3[0] = mfma_bf(du2l[0].hl, v3r.lh, ac.p3[0]);
+        ac.p3[1] = mfma_bf(du2l[1].hl, v3r.lh, ac.p3[1]);
+        ac.p3[0] = mfma_bf(du2l[0].hm, v3r.mh, ac.p3[0]);
+        ac.p3[1] = mfma_bf(du2l[1].hm, v3r.mh, ac.p3[1]);
+        ac.p3[0] = mfma_bf(du2l[0].hm, v3r.hm, ac.p3[0]);
+        ac.p3[1] = mfma_bf(du2l[1].hm, v3r.hm, ac.p3[1]);
+        __builtin_amdgcn_wave_barrier();
+        // p1 = v1 x g: the g tile (column g < 2 of row j) and v1; runs beside the next tile's forward
+        if (g < 2) *reinterpret_cast<float *>(ad.cst) = ghb;
+        park_p1(ad, v1);
+        if (unit_ends) {
+            // the unit's partial sums leave the wave: the pending p1 first, then an empty g tile so that the next
+            // tile's deferred p1 adds nothing
+            P1R last;
+            read_p1(last, ad);
+            mfma_p1(ac, last);
+            if (g < 2) *reinterpret_cast<float *>(ad.cst) = 0.f;
+            __builtin_amdgcn_wave_barrier();
+            float *out = partial + (size_t)unit_now * (GP_PART * 64) + lane;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) out[64 * c] = ac.p1[c] + ac.p1b[c];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) out[64 * (4 + (2 * t + u) * 4 + r)] = ac.p2[t][u][r];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) out[64 * (36 + 4 * u + r)] = ac.p3[u][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) out[64 * (44 + r)] = dw4[r];
+            zero_accum(ac);
+            dw4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
+// grads (one slab row per workgroup, flat layout) = sum over this workgroup's units of c_row(unit) * partial[unit]
+__global__ __launch_bounds__(256) void k_gp_combine(const float *__restrict__ partial, const float *__restrict__ rowc,
+                                                    unsigned n_units, unsigned n_big, unsigned tpr, float *__restrict__ slab) {
+    __shared__ float row[C_SLAB];
+    constexpr int PER = GP_PART * 64 / 256;       // 12 values per thread
+    float acc[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) acc[k] = 0.f;
+    for (unsigned u = blockIdx.x; u < n_units; u += gridDim.x) {
+        const unsigned first = u < n_big ? u * TileQueue::BIG : n_big * TileQueue::BIG + (u - n_big) * TileQueue::SMALL;
+        const float c = rowc[first / tpr];
+        const float *src = partial + (size_t)u * (GP_PART * 64) + threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < PER; ++k) acc[k] = __builtin_fmaf(c, src[256 * k], acc[k]);
+    }
+    for (int e = threadIdx.x; e < C_SLAB; e += 256) row[e] = 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = 256 * k + threadIdx.x, part = idx >> 6, lane = idx & 63, j = lane & 15, g = lane >> 4;
+        const float v = acc[k];
+        if (part < 4) {
+            if (part < 2) row[C_W1 + lane * 4 + part] = v;         // columns 2, 3 of W1 get no contribution
+        } else if (part < 36) {
+            const int q = part - 4, t = q >> 3, u = (q >> 2) & 1, r = q & 3;
+            row[C_W2 + (16 * u + j) * 64 + 16 * t + 4 * g + r] = v;
+        } else if (part < 44) {
+            const int q = part - 36, u = q >> 2, r = q & 3;
+            row[C_W3 + j * 32 + 16 * u + 4 * g + r] = v;
+        } else {
+            atomicAdd(&row[C_W4 + 4 * g + (part - 44)], v);          // sum over the 16 samples of a lane group
+        }
+    }
+    __syncthreads();
+    float *out = slab + (size_t)blockIdx.x * C_SLAB;
+    for (int e = threadIdx.x; e < C_SLAB; e += 256) out[e] = row[e];
+}
+#endif
+
 int grid_tiles(int64_t N, int per_cu, int waves = WAVES) {
     int64_t blocks = (((N + 15) >> 4) + waves - 1) / waves;
 #ifdef ABL_ONE_WAVE
@@ -1823,6 +2042,9 @@ static int init_attrs() {
     rc = rc ? rc : allow_big_lds(k_critic_bwd_mfma<true, false>, BIG_LDS);
     rc = rc ? rc : allow_big_lds(k_gp_c_mfma<true>, BIG_LDS);
     rc = rc ? rc : allow_big_lds(k_gp_c_mfma<false>, BIG_LDS);
+#if CRITIC_OUTER_BF16
+    rc = rc ? rc : allow_big_lds(k_gp_fused_mfma, BIG_LDS);
+#endif
     if (rc == DPD_OK) once.mark(dev);
     return rc;
 }
@@ -1876,9 +2098,31 @@ int critic_mfma_backward(const float *x, const float *cond, int64_t N, const flo
 
 // ws layout: slab (512 rows) | mask words [ntiles * 64] | g [N] float2 | tile_sq [ntiles] | rowc [B] | pen [B] |
 //            tile counters of pass A and pass C (inside the 1024 spare bytes)
+int g_gp_fused = 1;               // dpd_set_option("gp_fused", 0 / 1): the one-pass form where the shape allows it
+
+// rows of a multiple of 32 tiles: no hand-out unit crosses a row
+static bool gp_fused_shape(int64_t L) {
+#if CRITIC_OUTER_BF16
+    return g_gp_fused && L >= 512 && (L & 511) == 0;
+#else
+    return false;
+#endif
+}
+static void gp_units(int64_t nt, unsigned *n_big, unsigned *n_units) {
+    *n_big = (unsigned)((nt - (nt >> 3)) / TileQueue::BIG);
+    *n_units = *n_big + (unsigned)((nt - (int64_t)*n_big * TileQueue::BIG + TileQueue::SMALL - 1) / TileQueue::SMALL);
+}
+// fused form: slab (512 rows) | partials [units][48][64] | tile_sq [ntiles] | rowc [B] | pen [B] | combine slab (256 rows) | counter
+static size_t gp_fused_ws_bytes(int64_t B, int64_t L) {
+    const int64_t N = B * L, nt = (N + 15) >> 4;
+    unsigned n_big, n_units;
+    gp_units(nt, &n_big, &n_units);
+    return (size_t)512 * C_SLAB * 4 + (size_t)n_units * 48 * 64 * 4 + (size_t)nt * 4 + (size_t)B * 8 + (size_t)256 * C_SLAB * 4 + 1024;
+}
 size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L) {
     const int64_t N = B * L, nt = (N + 15) >> 4;
-    return (size_t)512 * C_SLAB * 4 + (size_t)nt * 64 * 4 + (size_t)N * 8 + (size_t)nt * 4 + (size_t)B * 8 + 1024;
+    const size_t three_pass = (size_t)512 * C_SLAB * 4 + (size_t)nt * 64 * 4 + (size_t)N * 8 + (size_t)nt * 4 + (size_t)B * 8 + 1024;
+    return gp_fused_shape(L) ? gp_fused_ws_bytes(B, L) : three_pass;
 }
 
 int critic_mfma_gp(const float *real, const float *fake, const float *cond, const float *alpha, int64_t B, int64_t L,
@@ -1897,6 +2141,32 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
     int rc = init_attrs();
     if (rc) return rc;
     unsigned *queue;
+#if CRITIC_OUTER_BF16
+    if (gp_fused_shape(L)) {
+        unsigned n_big, n_units;
+        gp_units(nt, &n_big, &n_units);
+        size_t o = (size_t)512 * C_SLAB * 4;
+        float *partial = reinterpret_cast<float *>(base + o); o += (size_t)n_units * 48 * 64 * 4;
+        float *sq = reinterpret_cast<float *>(base + o); o += (size_t)nt * 4;
+        float *rc_row = reinterpret_cast<float *>(base + o); o += (size_t)B * 4;
+        float *pen_row = reinterpret_cast<float *>(base + o); o += (size_t)B * 4;
+        float *cslab = reinterpret_cast<float *>(base + o); o += (size_t)256 * C_SLAB * 4;
+        rc = tile_counter(reinterpret_cast<unsigned *>(base + ((o + 63) & ~(size_t)63)), st, &queue);
+        if (rc) return rc;
+        const int gf = grid_tiles(N, WG_PER_CU, WG_WAVES);
+        hipLaunchKernelGGL(k_gp_fused_mfma, dim3(gf), dim3(WG_WAVES * 64), BIG_LDS, st, real, fake, cond, alpha, N, L, wb, slope,
+                           partial, sq, queue);
+        DPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_gp_rows_tiles, dim3(grid_for(B, 1, 4096)), dim3(64), 0, st, sq, B, L / 16, rownorm, rc_row, pen_row);
+        DPD_LAUNCH_CHECK();
+        hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, pen_row, (int)B, gp, 1.0f / (float)B);
+        DPD_LAUNCH_CHECK();
+        const int gcomb = n_units < 256 ? (int)n_units : 256;
+        hipLaunchKernelGGL(k_gp_combine, dim3(gcomb), dim3(256), 0, st, partial, rc_row, n_units, n_big, (unsigned)(L / 16), cslab);
+        DPD_LAUNCH_CHECK();
+        return gen_reduce_slab_generic(cslab, gcomb, C_SLAB, C_NP, grads, nullptr, 1.f, st);
+    }
+#endif
     rc = tile_counter(counters, st, &queue);
     if (rc) return rc;
     unsigned *queue_c = queue ? queue + 1 : nullptr;

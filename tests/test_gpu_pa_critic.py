@@ -146,9 +146,10 @@ def test_gradient_penalty_and_losses_golden(critic_impl):
     assert torch.isfinite(compute_gradient_penalty(d, real, fake, cond, dev))
 
 
-@pytest.mark.parametrize("shape", [(3, 1), (37, 1), (5, 77), (2, 1024), (3, 48)])
+@pytest.mark.parametrize("shape", [(3, 1), (37, 1), (5, 77), (2, 1024), (3, 48), (3, 512), (5, 1536)])
 def test_gradient_penalty_vs_oracle_ragged(shape, critic_impl):
-    """Row lengths that are not multiples of the 64-sample tile; [B, 2] inputs are rows of one sample."""
+    """Row lengths that are not multiples of the 64-sample tile; [B, 2] inputs are rows of one sample; rows of a
+    multiple of 512 samples take the one-pass kernel of the MFMA family."""
     from oracle import critic as oc
     from dpd_amd.models import Discriminator, compute_gradient_penalty
     B, Lr = shape
@@ -177,6 +178,42 @@ def test_gradient_penalty_vs_oracle_ragged(shape, critic_impl):
     gp.backward()
     for lin, rg in zip(d._layers(), ref_g):
         close(lin.weight_orig.grad, rg, rtol=3e-4, atol=3e-6)
+
+
+@pytest.mark.parametrize("shape", [(1, 512), (9, 1024), (70, 512), (33, 2048)])
+def test_gradient_penalty_one_pass_matches_three_pass(shape):
+    """dpd_critic_gp on rows of a multiple of 512 samples: the one-pass kernel (unscaled reverse chain, row coefficients
+    applied to per-unit partial sums) against the three-pass form (dpd_set_option("gp_fused", 0)), through the C ABI."""
+    from dpd_amd import _lib as L
+    B, Lr = shape
+    N = B * Lr
+    torch.manual_seed(11)
+    real, fake, cond = ((torch.randn(N, 2, device=DEV) * 0.4).contiguous() for _ in range(3))
+    alpha = torch.rand(B, device=DEV)
+    wb = torch.randn(2945, device=DEV) * 0.2
+    ws, wsp, wsn = L.workspace(DEV, N)
+    st = L.stream()
+
+    def run():
+        gp, rn, gg = torch.zeros(1, device=DEV), torch.empty(B, device=DEV), torch.empty(2945, device=DEV)
+        L.call("dpd_critic_gp", L.fptr(real), L.fptr(fake), L.fptr(cond), L.fptr(alpha), B, Lr, L.fptr(wb), 0.2, L.fptr(gp),
+               L.fptr(rn), L.fptr(gg), wsp, wsn, st)
+        torch.cuda.synchronize()
+        return gp.cpu(), rn.cpu(), gg.cpu()
+    L.call("dpd_set_option", b"critic_impl", 2)        # the MFMA family whatever the size
+    try:
+        one = run()
+        L.call("dpd_set_option", b"gp_fused", 0)
+        try:
+            three = run()
+        finally:
+            L.call("dpd_set_option", b"gp_fused", 1)
+    finally:
+        L.call("dpd_set_option", b"critic_impl", 0)
+    assert torch.equal(one[1], three[1])                # row norms: the same arithmetic in both forms
+    close(one[0], three[0].numpy(), rtol=1e-6)
+    close(one[2], three[2].numpy(), rtol=2e-5, atol=2e-6 * float(three[2].abs().max()))
+    assert float(three[2].abs().max()) > 0
 
 
 @pytest.mark.parametrize("n", [1, 15, 16, 17, 1000, 4099, 600013])
