@@ -64,8 +64,9 @@ constexpr int Q_W4 = 17;    //                e = r : W4[4g + r] (VALU operand)
 constexpr int QB_A2 = 18;   // [u][q][term]   W2[16u + i][neuron(q, g, e)], neuron = 16(2q + (e >> 2)) + 4g + (e & 3)
 constexpr int QB_A3 = 30;   // [term]         W3[i][16(e >> 2) + 4g + (e & 3)]
 constexpr int QB_A2T = 33;  // [t][term]      W2[16(e >> 2) + 4g + (e & 3)][16t + i]
-constexpr int QB_A3T = 45;  // [term]         W3[4g + (e & 3)][16(e >> 2) + i]  (two 16x16x16 operands in one entry)
-constexpr int NQUAD = 48;
+constexpr int QB_A3T = 45;  // [u][pair]      W3[4g + (e & 3)][16u + i], term h for e < 4, l (pair 0) or m (pair 1) for e >= 4:
+                            //                K = 32 = the 16 layer-3 neurons in two terms (see chain_top)
+constexpr int NQUAD = 49;
 #else
 constexpr int Q_A1 = 0;     // [t]            e = t : W1[16t + i][g]
 constexpr int Q_A2 = 1;     // [u][t]         e = r : W2[16u + i][16t + 4g + r]
@@ -147,7 +148,7 @@ DEV void build_image(float *img, const float *__restrict__ wb) {
                 if (q < QB_A3) { int k = q - QB_A2; term = k % 3; int u = k / 6, qq = (k / 3) & 1; x = wb[C_W2 + (16 * u + i) * 64 + 32 * qq + n]; }
                 else if (q < QB_A2T) { term = q - QB_A3; x = wb[C_W3 + i * 32 + n]; }
                 else if (q < QB_A3T) { int k = q - QB_A2T; term = k % 3; int t = k / 3; x = wb[C_W2 + n * 64 + 16 * t + i]; }
-                else { term = q - QB_A3T; x = wb[C_W3 + (4 * g + (e & 3)) * 32 + 16 * (e >> 2) + i]; }
+                else { int k = q - QB_A3T; term = e < 4 ? 0 : ((k & 1) ? 1 : 2); x = wb[C_W3 + (4 * g + (e & 3)) * 32 + 16 * (k >> 1) + i]; }
                 __bf16 h, m, l;
                 split3(x, h, m, l);
                 v[e] = term == 0 ? h : (term == 1 ? m : l);
@@ -348,8 +349,8 @@ struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 for the VAL
     f32x4 b3, w4;
     B3 w;
 };
-struct TopOps {        // W3^T: both 16-row tiles of a 16x16x16 operand in one entry per term
-    bf16x8 t[3];
+struct TopOps {        // W3^T, 16-row tile u: [h|l] in t[2u], [h|m] in t[2u + 1]
+    bf16x8 t[4];
 };
 struct BotOps {        // W2^T, row tiles 0 and 1
     B3 w[2];
@@ -370,7 +371,7 @@ DEV void load_ops(Fc3Ops &o, const float *img, int lane) {
 }
 DEV void load_ops(TopOps &o, const float *img, int lane) {
 #pragma unroll
-    for (int k = 0; k < 3; ++k) o.t[k] = bquad(img, QB_A3T + k, lane);
+    for (int k = 0; k < 4; ++k) o.t[k] = bquad(img, QB_A3T + k, lane);
 }
 DEV void load_ops(BotOps &o, const float *img, int lane) {
     load_b3(o.w[0], img, QB_A2T, lane);
@@ -446,7 +447,8 @@ DEV f32x4 fc3_product(const f32x4 &x0, const f32x4 &x1, const B3 &w, f32x4 start
     return start + lo;
 }
 // FC3 and the last layer (16 -> 1), which runs on the VALU: four FMAs per lane and a sum over the lane groups
-template <bool BITS = false, class Pre, class Keep = NoKeep>
+// SCORE = false: the caller wants the activations and masks only (the gradient penalty)
+template <bool BITS = false, bool SCORE = true, class Pre, class Keep = NoKeep>
 DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc3Ops &o, Pre pre,
                       unsigned long long *ts = nullptr, Keep keep = Keep()) {
     TS(7)
@@ -456,6 +458,7 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
     FENCE();
     TS(8)
     act4<BITS>(y, slope, a.h3, a.m3, a.bits, 24);
+    if (!SCORE) return;
     float s = o.w4[0] * a.h3[0];
 #pragma unroll
     for (int r = 1; r < 4; ++r) s = __builtin_fmaf(o.w4[r], a.h3[r], s);
@@ -465,7 +468,7 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
 
 // back-propagation of an upstream vector through the three hidden layers, in two steps:
 //   top[r] (16 values on neurons 4g + r of layer 3, already masked) -> d2[2] (layer 2, masked) -> d1[4] (layer 1, masked)
-// The first step contracts over 16 neurons: v_mfma_f32_16x16x16_bf16, whose k = 4g + e is what a lane holds.
+// The first step contracts over the 16 layer-3 neurons, four per lane group (k = 4g + e is what a lane holds).
 // The MFMAs of one wave and the VALU instructions of another wave of the same SIMD do not overlap on this part
 // (scratch/ubench/cross_wave_overlap.hip: their times add up), so a burst of MFMAs hides nothing unless the
 // wave itself has independent VALU work in the same stretch of code.  Hence the order here: the first 16-row
@@ -486,32 +489,22 @@ DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], B3 &sd2, con
     split_pair(top[0], top[1], bh[0], bm[0], bl[0]);
     split_pair(top[2], top[3], bh[1], bm[1], bl[1]);
     keep(bh, bm, bl);
-    const s16x4 b[3] = {__builtin_bit_cast(s16x4, u32x2{bh[0], bh[1]}), __builtin_bit_cast(s16x4, u32x2{bm[0], bm[1]}),
-                        __builtin_bit_cast(s16x4, u32x2{bl[0], bl[1]})};
+    // The contraction runs over the 16 layer-3 neurons only, so a K = 32 instruction takes two terms per operand
+    // (k-slots 0..3 of a lane group: one term of neurons 4g..4g+3, slots 4..7: another term of the same neurons)
+    // and three instructions give the six products: [h|l] x [l|h], [h|m] x [m|h], [h|m] x [h|m] (weights first).
+    const bf16x8 b_lh = __builtin_bit_cast(bf16x8, u32x4{bl[0], bl[1], bh[0], bh[1]});
+    const bf16x8 b_mh = __builtin_bit_cast(bf16x8, u32x4{bm[0], bm[1], bh[0], bh[1]});
+    const bf16x8 b_hm = __builtin_bit_cast(bf16x8, u32x4{bh[0], bh[1], bm[0], bm[1]});
     FENCE();
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
-    // products in the order mm, lh, hl, mh, hm, hh (term of the weights, term of the activations)
-    const int ta[6] = {1, 2, 0, 1, 0, 0}, tb[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const s16x8 w = __builtin_bit_cast(s16x8, o.t[ta[k]]);
-#ifdef ABL_NO_MFMA
-        asm volatile("" : "+v"(e0) : "v"(w), "v"(b[tb[k]]));
-#else
-        e0 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[0], w[1], w[2], w[3]}, b[tb[k]], e0, 0, 0, 0);
-#endif
-    }
+    e0 = mfma_bf(o.t[0], b_lh, e0);
+    e0 = mfma_bf(o.t[1], b_mh, e0);
+    e0 = mfma_bf(o.t[1], b_hm, e0);
     FENCE();
     unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-        const s16x8 w = __builtin_bit_cast(s16x8, o.t[ta[k]]);
-#ifdef ABL_NO_MFMA
-        asm volatile("" : "+v"(e1) : "v"(w), "v"(b[tb[k]]));
-#else
-        e1 = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(s16x4{w[4], w[5], w[6], w[7]}, b[tb[k]], e1, 0, 0, 0);
-#endif
-    }
+    e1 = mfma_bf(o.t[2], b_lh, e1);
+    e1 = mfma_bf(o.t[3], b_mh, e1);
+    e1 = mfma_bf(o.t[3], b_hm, e1);
     d2[0] = e0 * m2[0];
     split_pair(d2[0][0], d2[0][1], h[0], m[0], l[0]);
     split_pair(d2[0][2], d2[0][3], h[1], m[1], l[1]);
@@ -643,7 +636,7 @@ DEV void forward_front(Acts &a, const float *img, int lane, float in, float slop
     TS(6)
 }
 // FC3 and the last layer (16 -> 1), which runs on the VALU: four FMAs per lane and a sum over the lane groups
-template <bool BITS = false, class Pre>
+template <bool BITS = false, bool SCORE = true, class Pre>
 DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc3Ops &o, Pre pre,
                       unsigned long long *ts = nullptr) {
     TS(7)
@@ -658,6 +651,7 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
     FENCE();
     TS(8)
     act4<BITS>(y0 + y1, slope, a.h3, a.m3, a.bits, 24);
+    if (!SCORE) return;
     float s = o.w4[0] * a.h3[0];
 #pragma unroll
     for (int r = 1; r < 4; ++r) s = __builtin_fmaf(o.w4[r], a.h3[r], s);
@@ -1529,7 +1523,7 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         BotOps bot;
         InOps ino;
         forward_front<true>(a, lds, lane, in, slope, front, [&] { load_ops(o3, lds, lane); });
-        forward_back<true>(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
+        forward_back<true, false>(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
         const f32x4 (&m1)[4] = a.m1;
         const f32x4 (&m2)[2] = a.m2;
         const unsigned bits = a.bits;
@@ -1873,7 +1867,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
             read_p1(p1r, ad);
         });
         mfma_p1(ac, p1r);
-        forward_back(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
+        forward_back<false, false>(a, lds, lane, slope, o3, [&] { load_ops(top, lds, lane); });
         const f32x4 (&m1)[4] = a.m1;
         const f32x4 (&m2)[2] = a.m2;
         const f32x4 m3 = a.m3;

@@ -46,10 +46,10 @@ PA_FLOP = 200                                   # memory polynomial, 4 orders x 
 PA_BWD_FLOP = 400
 # MFMA instructions the critic's fused mean-score pass (forward + backward) issues per tile of 16 samples, with
 # their issue cycles per SIMD (counted in the kernel's assembly): FC1 runs on v_mfma_f32_16x16x4_f32 (4 x 32 cycles) and
-# the first-layer weight gradient on v_mfma_f32_4x4x1_16b_f32 (16 x 8); the hidden-layer products (54) and the weight
-# gradients of the two inner layers (30) as three-way-split bf16 operands on v_mfma_f32_16x16x32_bf16 (16 cycles), the
-# contraction over the 16 layer-3 neurons on v_mfma_f32_16x16x16_bf16 (12, priced at their peak rate of 8)
-CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + 84 * 16 + 12 * 8
+# the first-layer weight gradient on v_mfma_f32_4x4x1_16b_f32 (16 x 8); the hidden-layer products (60) and the weight
+# gradients of the two inner layers (30) as three-way-split bf16 operands on v_mfma_f32_16x16x32_bf16 (16 cycles)
+CRITIC_BWD_BF16_MFMA = 90
+CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + CRITIC_BWD_BF16_MFMA * 16
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
 
@@ -272,7 +272,7 @@ def run_stage2(ctx, args, steps, warmup):
     kflop = 2.0 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC) * n
     tiles_per_simd = n / 16.0 / N_SIMD
     issue_s = tiles_per_simd * CRITIC_BWD_MFMA_CYCLES / CLOCK_HZ
-    bf16_flop = (n / 16.0) * (84 * 2 * 16 * 16 * 32 + 12 * 2 * 16 * 16 * 16)
+    bf16_flop = (n / 16.0) * CRITIC_BWD_BF16_MFMA * 2 * 16 * 16 * 32
     roof = {"bound": "mfma",
             "kernel": "k_critic_bwd_mfma<true,false>: critic forward + backward with weight gradients in one pass "
                       "(10 of the step's launches); fp32 MFMA for FC1 and the first-layer weight gradient, hidden-layer "
@@ -281,13 +281,13 @@ def run_stage2(ctx, args, steps, warmup):
             # fp32 peak: the arithmetic is fp32-accurate, whichever matrix pipe carries it
             "achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kflop / k / 1e12 / FP32_PEAK_TFLOPS,
             "frac_definition": "algorithmic fp32 flops per launch / kernel time / fp32 MFMA peak (an fp32-equivalent rate, which "
-                               "can pass 1: 96 of the 116 MFMAs of a tile run on the bf16 pipe as split products of fp32 accuracy; "
+                               "can pass 1: 90 of the 110 MFMAs of a tile run on the bf16 pipe as split products of fp32 accuracy; "
                                "mfma_issue_frac and bf16_executed are the utilisations)",
             # utilisation: the time the kernel's MFMAs need at their own peak issue rates (fp32 157.3 TFLOP/s, bf16 2.5 PFLOP/s
             # dense) over the measured time
             "mfma_issue_frac": issue_s / k, "mfma_issue_ms": issue_s * 1e3, "kernel_ms": k * 1e3,
-            # the bf16 side by itself: flops the kernel's bf16 MFMAs execute (84 16x16x32 and 12 16x16x16 per tile of 16
-            # samples: six products per fp32-accurate product) over the kernel time, against the dense bf16 peak
+            # the bf16 side by itself: flops the kernel's bf16 MFMAs execute (90 16x16x32 per tile of 16 samples: six
+            # products per fp32-accurate product) over the kernel time, against the dense bf16 peak
             "bf16_executed": {"achieved": bf16_flop / k / 1e12, "peak": BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                               "frac": bf16_flop / k / 1e12 / BF16_PEAK_TFLOPS},
             "flop_per_sample": 2 * (CRITIC_FWD_MAC + CRITIC_BWD_MAC),
