@@ -1052,19 +1052,21 @@ DEV void combine_rows(float *lds, float *slab_row) {
 struct TileQueue {
     static constexpr unsigned BIG = TILE_UNIT_BIG, SMALL = TILE_UNIT_SMALL;
     unsigned *queue;
-    unsigned n_waves, static_next, n_big, len, in_unit, next_raw, unit;
+    unsigned n_waves, static_next, n_big, big, len, in_unit, next_raw, unit;
     int64_t base;                                 // first tile of the current unit
-    DEV void start(unsigned u) {                  // unit u: BIG tiles each below n_big, SMALL from there on
+    DEV void start(unsigned u) {                  // unit u: `big` tiles each below n_big, SMALL from there on
         unit = u;
-        len = u < n_big ? BIG : SMALL;
-        base = u < n_big ? (int64_t)u * BIG : (int64_t)n_big * BIG + (int64_t)(u - n_big) * SMALL;
+        len = u < n_big ? big : SMALL;
+        base = u < n_big ? (int64_t)u * big : (int64_t)n_big * big + (int64_t)(u - n_big) * SMALL;
         in_unit = 0;
     }
-    DEV void init(unsigned *q, unsigned first, unsigned waves, int64_t ntiles) {
+    // big_tiles: BIG, or SMALL where a unit must not be longer (rows of an odd multiple of 16 tiles in k_gp_fused_mfma)
+    DEV void init(unsigned *q, unsigned first, unsigned waves, int64_t ntiles, unsigned big_tiles = BIG) {
         queue = q;
         n_waves = waves;
         static_next = first;
-        n_big = (unsigned)((ntiles - (ntiles >> 3)) / BIG);
+        big = big_tiles;
+        n_big = (unsigned)((ntiles - (ntiles >> 3)) / big);
         next_raw = 0;
         start(first);
     }
@@ -1797,12 +1799,15 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
 //   d gp / dW = sum over rows b of c_b * G_b,   G_b = sum over the samples of row b of (terms in g, not in c_b),
 // so the reverse chain of pass C can run with the unscaled input gradient g in the same kernel that computes g, and
 // the coefficient is applied afterwards to partial sums that do not cross a row: every hand-out unit (32 or 16
-// tiles; rows are a multiple of 32 tiles here, so a unit lies inside one row) writes its own partial weight
+// tiles; rows are a multiple of 16 tiles here and units of 32 are used only when they are a multiple of 32, so a unit
+// lies inside one row) writes its own partial weight
 // gradient, in accumulator layout, and k_gp_combine forms sum_u c_row(u) * partial[u].  Against the three-pass form
 // this saves the second evaluation of the v-chain (36 MFMAs and its splits), packing and unpacking the mask
 // bits, the mask words and g in HBM, and a launch: 150 instead of 186 MFMAs, about 600 instead of 770 VALU
 // instructions per tile.
 constexpr int GP_PART = 48;          // floats per lane of a partial: W1 gradient 4, W2 gradient 32, W3 gradient 8, W4 gradient 4
+// longest unit that stays inside a row of tpr tiles (tpr is a multiple of SMALL)
+__host__ DEV unsigned gp_big_unit(unsigned tpr) { return tpr % TileQueue::BIG == 0 ? TileQueue::BIG : TileQueue::SMALL; }
 __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(const float *__restrict__ real, const float *__restrict__ fake,
                                                               const float *__restrict__ cond, const float *__restrict__ alpha,
                                                               int64_t N, int64_t L, const float *__restrict__ wb, float slope,
@@ -1842,7 +1847,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
     FrontOps front;
     load_ops(front, lds, lane);
     TileQueue tq;
-    tq.init(queue, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, ntiles);
+    tq.init(queue, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, ntiles, gp_big_unit(tpr));
     int64_t tile_next = tq.tile();
     Raw raw_next = fetch(tile_next);
     while (tile_next < ntiles) {
@@ -1972,14 +1977,15 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
 
 // grads (one slab row per workgroup, flat layout) = sum over this workgroup's units of c_row(unit) * partial[unit]
 __global__ __launch_bounds__(256) void k_gp_combine(const float *__restrict__ partial, const float *__restrict__ rowc,
-                                                    unsigned n_units, unsigned n_big, unsigned tpr, float *__restrict__ slab) {
+                                                    unsigned n_units, unsigned n_big, unsigned big, unsigned tpr,
+                                                    float *__restrict__ slab) {
     __shared__ float row[C_SLAB];
     constexpr int PER = GP_PART * 64 / 256;       // 12 values per thread
     float acc[PER];
 #pragma unroll
     for (int k = 0; k < PER; ++k) acc[k] = 0.f;
     for (unsigned u = blockIdx.x; u < n_units; u += gridDim.x) {
-        const unsigned first = u < n_big ? u * TileQueue::BIG : n_big * TileQueue::BIG + (u - n_big) * TileQueue::SMALL;
+        const unsigned first = u < n_big ? u * big : n_big * big + (u - n_big) * TileQueue::SMALL;
         const float c = rowc[first / tpr];
         const float *src = partial + (size_t)u * (GP_PART * 64) + threadIdx.x;
 #pragma unroll
@@ -2094,23 +2100,28 @@ int critic_mfma_backward(const float *x, const float *cond, int64_t N, const flo
 //            tile counters of pass A and pass C (inside the 1024 spare bytes)
 int g_gp_fused = 1;               // dpd_set_option("gp_fused", 0 / 1): the one-pass form where the shape allows it
 
-// rows of a multiple of 32 tiles: no hand-out unit crosses a row
+// rows of a multiple of 16 tiles: no hand-out unit crosses a row (units of 32 tiles only if rows are a multiple of 32)
 static bool gp_fused_shape(int64_t L) {
 #if CRITIC_OUTER_BF16
-    return g_gp_fused && L >= 512 && (L & 511) == 0;
+    return g_gp_fused && L >= 256 && (L & 255) == 0;
 #else
     return false;
 #endif
 }
-static void gp_units(int64_t nt, unsigned *n_big, unsigned *n_units) {
-    *n_big = (unsigned)((nt - (nt >> 3)) / TileQueue::BIG);
-    *n_units = *n_big + (unsigned)((nt - (int64_t)*n_big * TileQueue::BIG + TileQueue::SMALL - 1) / TileQueue::SMALL);
+#if CRITIC_OUTER_BF16
+static void gp_units(int64_t nt, int64_t L, unsigned *n_big, unsigned *n_units) {
+    const unsigned big = gp_big_unit((unsigned)(L >> 4));
+    *n_big = (unsigned)((nt - (nt >> 3)) / big);
+    *n_units = *n_big + (unsigned)((nt - (int64_t)*n_big * big + TileQueue::SMALL - 1) / TileQueue::SMALL);
 }
+#endif
 // fused form: slab (512 rows) | partials [units][48][64] | tile_sq [ntiles] | rowc [B] | pen [B] | combine slab (256 rows) | counter
 static size_t gp_fused_ws_bytes(int64_t B, int64_t L) {
     const int64_t N = B * L, nt = (N + 15) >> 4;
-    unsigned n_big, n_units;
-    gp_units(nt, &n_big, &n_units);
+    unsigned n_big = 0, n_units = 0;
+#if CRITIC_OUTER_BF16
+    gp_units(nt, L, &n_big, &n_units);
+#endif
     return (size_t)512 * C_SLAB * 4 + (size_t)n_units * 48 * 64 * 4 + (size_t)nt * 4 + (size_t)B * 8 + (size_t)256 * C_SLAB * 4 + 1024;
 }
 size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L) {
@@ -2138,7 +2149,7 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
 #if CRITIC_OUTER_BF16
     if (gp_fused_shape(L)) {
         unsigned n_big, n_units;
-        gp_units(nt, &n_big, &n_units);
+        gp_units(nt, L, &n_big, &n_units);
         size_t o = (size_t)512 * C_SLAB * 4;
         float *partial = reinterpret_cast<float *>(base + o); o += (size_t)n_units * 48 * 64 * 4;
         float *sq = reinterpret_cast<float *>(base + o); o += (size_t)nt * 4;
@@ -2156,7 +2167,8 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
         hipLaunchKernelGGL(k_sum_partials, dim3(1), dim3(256), 0, st, pen_row, (int)B, gp, 1.0f / (float)B);
         DPD_LAUNCH_CHECK();
         const int gcomb = n_units < 256 ? (int)n_units : 256;
-        hipLaunchKernelGGL(k_gp_combine, dim3(gcomb), dim3(256), 0, st, partial, rc_row, n_units, n_big, (unsigned)(L / 16), cslab);
+        hipLaunchKernelGGL(k_gp_combine, dim3(gcomb), dim3(256), 0, st, partial, rc_row, n_units, n_big,
+                           gp_big_unit((unsigned)(L / 16)), (unsigned)(L / 16), cslab);
         DPD_LAUNCH_CHECK();
         return gen_reduce_slab_generic(cslab, gcomb, C_SLAB, C_NP, grads, nullptr, 1.f, st);
     }

@@ -60,7 +60,7 @@ int dpd_version(void);
  * carries the last four generator outputs of a chunk over to the next, so no output is computed twice; 0 = chunks of 60
  * PA outputs that overlap by four generator outputs (any wave can take any chunk); 2 (default) = 1 when the batch has
  * enough rows to fill the waves evenly, else 0.  The results agree to fp32 rounding (same arithmetic per output).
- * "gp_fused": 1 (default) = dpd_critic_gp on rows of a multiple of 512 samples runs forward, input gradient and the
+ * "gp_fused": 1 (default) = dpd_critic_gp on rows of a multiple of 256 samples runs forward, input gradient and the
  * reverse chain in one pass over the samples and applies the row coefficients to per-unit partial sums afterwards;
  * 0 = the three-pass form for every shape.  Same results to fp32 summation order. */
 int dpd_set_option(const char *name, int value);

@@ -146,10 +146,10 @@ def test_gradient_penalty_and_losses_golden(critic_impl):
     assert torch.isfinite(compute_gradient_penalty(d, real, fake, cond, dev))
 
 
-@pytest.mark.parametrize("shape", [(3, 1), (37, 1), (5, 77), (2, 1024), (3, 48), (3, 512), (5, 1536)])
+@pytest.mark.parametrize("shape", [(3, 1), (37, 1), (5, 77), (2, 1024), (3, 48), (3, 512), (5, 1536), (6, 256)])
 def test_gradient_penalty_vs_oracle_ragged(shape, critic_impl):
     """Row lengths that are not multiples of the 64-sample tile; [B, 2] inputs are rows of one sample; rows of a
-    multiple of 512 samples take the one-pass kernel of the MFMA family."""
+    multiple of 256 samples take the one-pass kernel of the MFMA family."""
     from oracle import critic as oc
     from dpd_amd.models import Discriminator, compute_gradient_penalty
     B, Lr = shape
@@ -180,9 +180,9 @@ def test_gradient_penalty_vs_oracle_ragged(shape, critic_impl):
         close(lin.weight_orig.grad, rg, rtol=3e-4, atol=3e-6)
 
 
-@pytest.mark.parametrize("shape", [(1, 512), (9, 1024), (70, 512), (33, 2048)])
+@pytest.mark.parametrize("shape", [(1, 512), (9, 1024), (70, 512), (33, 2048), (40, 256), (21, 768)])
 def test_gradient_penalty_one_pass_matches_three_pass(shape):
-    """dpd_critic_gp on rows of a multiple of 512 samples: the one-pass kernel (unscaled reverse chain, row coefficients
+    """dpd_critic_gp on rows of a multiple of 256 samples: the one-pass kernel (unscaled reverse chain, row coefficients
     applied to per-unit partial sums) against the three-pass form (dpd_set_option("gp_fused", 0)), through the C ABI."""
     from dpd_amd import _lib as L
     B, Lr = shape
