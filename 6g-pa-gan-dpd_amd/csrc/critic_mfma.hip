@@ -1980,6 +1980,7 @@ __global__ __launch_bounds__(256) void k_gp_combine(const float *__restrict__ pa
                                                     unsigned n_units, unsigned n_big, unsigned big, unsigned tpr,
                                                     float *__restrict__ slab) {
     __shared__ float row[C_SLAB];
+    __shared__ float w4part[4 * 64];              // W4 gradient per lane, summed over the 16 samples of a lane group below
     constexpr int PER = GP_PART * 64 / 256;       // 12 values per thread
     float acc[PER];
 #pragma unroll
@@ -2006,8 +2007,16 @@ __global__ __launch_bounds__(256) void k_gp_combine(const float *__restrict__ pa
             const int q = part - 36, u = q >> 2, r = q & 3;
             row[C_W3 + j * 32 + 16 * u + 4 * g + r] = v;
         } else {
-            atomicAdd(&row[C_W4 + 4 * g + (part - 44)], v);          // sum over the 16 samples of a lane group
+            w4part[64 * (part - 44) + lane] = v;
         }
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {       // (g, r): the 16 samples of the lane group in a fixed order
+        const int g = threadIdx.x >> 2, r = threadIdx.x & 3;
+        float sum = 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sum += w4part[64 * r + 16 * g + j];
+        row[C_W4 + 4 * g + r] = sum;
     }
     __syncthreads();
     float *out = slab + (size_t)blockIdx.x * C_SLAB;
