@@ -203,6 +203,7 @@ def test_gradient_penalty_one_pass_matches_three_pass(shape):
     L.call("dpd_set_option", b"critic_impl", 2)        # the MFMA family whatever the size
     try:
         one = run()
+        again = run()
         L.call("dpd_set_option", b"gp_fused", 0)
         try:
             three = run()
@@ -210,6 +211,7 @@ def test_gradient_penalty_one_pass_matches_three_pass(shape):
             L.call("dpd_set_option", b"gp_fused", 1)
     finally:
         L.call("dpd_set_option", b"critic_impl", 0)
+    assert all(torch.equal(a, b) for a, b in zip(one, again))   # per-unit partial sums, combined in a fixed order
     assert torch.equal(one[1], three[1])                # row norms: the same arithmetic in both forms
     close(one[0], three[0].numpy(), rtol=1e-6)
     close(one[2], three[2].numpy(), rtol=2e-5, atol=2e-6 * float(three[2].abs().max()))
