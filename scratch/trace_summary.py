@@ -7,7 +7,7 @@ import collections
 rows = list(csv.DictReader(open(sys.argv[1])))
 steps = int(sys.argv[2])
 ev = sorted((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in rows)
-ia = [i for i, e in enumerate(ev) if 'k_gp_a_mfma' in e[2]]
+ia = [i for i, e in enumerate(ev) if 'k_gp_a_mfma' in e[2] or 'k_gp_fused_mfma' in e[2]]
 # last `steps` steps: 5 penalty passes each
 a = ia[-5 * steps]
 sub = ev[a:]
