@@ -94,6 +94,43 @@ def test_critic_mean_score_additive_and_gp_row_independent(big):
     close(gp, gp_p.detach().cpu().numpy(), rtol=1e-5, atol=0)
 
 
+def test_gradient_penalty_one_pass_and_three_pass_agree_at_full_size(big):
+    """dpd_critic_gp on the benchmark's 16384 rows x 1024 samples: the one-pass kernel against the three-pass form,
+    and the weight gradient additive over a split of the rows (the penalty is a mean over rows)."""
+    from dpd_amd import _lib as L
+    _, iq, _ = big
+    real = iq[:, 5:, :].contiguous()
+    fake, cond = (real * 1.1).contiguous(), (real * 0.8).contiguous()
+    B, Lr = real.shape[0], real.shape[1]
+    alpha = torch.rand(B, device=DEV, generator=torch.Generator(device=DEV).manual_seed(3))
+    torch.manual_seed(6)
+    wb = torch.randn(2945, device=DEV) * 0.2
+    ws, wsp, wsn = L.workspace(DEV, B * Lr)
+    st = L.stream()
+
+    def run(lo, hi):
+        n = hi - lo
+        gp, rn, gg = torch.zeros(1, device=DEV), torch.empty(n, device=DEV), torch.empty(2945, device=DEV)
+        L.call("dpd_critic_gp", L.fptr(real[lo:hi]), L.fptr(fake[lo:hi]), L.fptr(cond[lo:hi]), L.fptr(alpha[lo:hi]), n, Lr,
+               L.fptr(wb), 0.2, L.fptr(gp), L.fptr(rn), L.fptr(gg), wsp, wsn, st)
+        torch.cuda.synchronize()
+        return gp.cpu(), rn.cpu(), gg.cpu()
+    one = run(0, B)
+    L.call("dpd_set_option", b"gp_fused", 0)
+    try:
+        three = run(0, B)
+    finally:
+        L.call("dpd_set_option", b"gp_fused", 1)
+    assert torch.equal(one[1], three[1])
+    close(one[0], three[0].numpy(), rtol=1e-6)
+    scale = float(three[2].abs().max())
+    assert scale > 0
+    close(one[2], three[2].numpy(), rtol=5e-5, atol=5e-6 * scale)
+    lo, hi = run(0, B // 2), run(B // 2, B)
+    close(one[0], (0.5 * (lo[0] + hi[0])).numpy(), rtol=1e-5)
+    close(one[2], (0.5 * (lo[2] + hi[2])).numpy(), rtol=1e-4, atol=5e-6 * scale)
+
+
 def test_spectral_statistics_scale_exactly(big):
     from dpd_amd import _lib as L
     from dpd_amd.utils.spectral_loss import band_masks
