@@ -1798,16 +1798,17 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
 // The weight gradient of the penalty is linear in the row coefficient c_b = 2(|g_b| - 1) / (|g_b| B):
 //   d gp / dW = sum over rows b of c_b * G_b,   G_b = sum over the samples of row b of (terms in g, not in c_b),
 // so the reverse chain of pass C can run with the unscaled input gradient g in the same kernel that computes g, and
-// the coefficient is applied afterwards to partial sums that do not cross a row: every hand-out unit (32 or 16
-// tiles; rows are a multiple of 16 tiles here and units of 32 are used only when they are a multiple of 32, so a unit
-// lies inside one row) writes its own partial weight
+// the coefficient is applied afterwards to partial sums that do not cross a row: every hand-out unit (64, 32 or 16
+// tiles; rows are a multiple of 16 tiles here and the longer units are used only when the rows are a multiple of
+// them, so a unit lies inside one row) writes its own partial weight
 // gradient, in accumulator layout, and k_gp_combine forms sum_u c_row(u) * partial[u].  Against the three-pass form
 // this saves the second evaluation of the v-chain (36 MFMAs and its splits), packing and unpacking the mask
 // bits, the mask words and g in HBM, and a launch: 150 instead of 186 MFMAs, about 600 instead of 770 VALU
 // instructions per tile.
 constexpr int GP_PART = 48;          // floats per lane of a partial: W1 gradient 4, W2 gradient 32, W3 gradient 8, W4 gradient 4
-// longest unit that stays inside a row of tpr tiles (tpr is a multiple of SMALL)
-__host__ DEV unsigned gp_big_unit(unsigned tpr) { return tpr % TileQueue::BIG == 0 ? TileQueue::BIG : TileQueue::SMALL; }
+// longest unit (of 64, 32, 16 tiles) that stays inside a row of tpr tiles (tpr is a multiple of SMALL = 16): fewer,
+// larger partials for long rows
+__host__ DEV unsigned gp_big_unit(unsigned tpr) { return tpr % 64 == 0 ? 64u : (tpr % 32 == 0 ? 32u : TileQueue::SMALL); }
 __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(const float *__restrict__ real, const float *__restrict__ fake,
                                                               const float *__restrict__ cond, const float *__restrict__ alpha,
                                                               int64_t N, int64_t L, const float *__restrict__ wb, float slope,
