@@ -51,7 +51,11 @@ constexpr int BWD_WORDS = SER_WORDS + 2 * TILE_W;   // 3736 words per wave
 static_assert(WAVES * BWD_WORDS >= WAVES * G_SLAB, "the gradient rows are combined in the staging LDS");
 static_assert((size_t)WAVES * BWD_WORDS * sizeof(float) <= 65536, "static LDS of the backward kernel: 58.4 KiB, two workgroups per CU");
 
+#ifdef ABL_NO_MFMA      // experiment (timing only, results are wrong): every matrix instruction dropped, its dependencies kept
+DEV f32x4 mfma4(float a, float b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
+#else
 DEV f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+#endif
 
 // reference feature index (models/tdnn_generator.py:176-193) of a slot; -1 for the two zero slots
 DEV int slot_ref(int slot) {
