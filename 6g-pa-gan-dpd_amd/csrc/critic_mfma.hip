@@ -1060,7 +1060,7 @@ struct TileQueue {
         base = u < n_big ? (int64_t)u * big : (int64_t)n_big * big + (int64_t)(u - n_big) * SMALL;
         in_unit = 0;
     }
-    // big_tiles: BIG, or SMALL where a unit must not be longer (rows of an odd multiple of 16 tiles in k_gp_fused_mfma)
+    // big_tiles: length of the long units (k_gp_fused_mfma picks 64, 32 or 16 so that no unit crosses a row)
     DEV void init(unsigned *q, unsigned first, unsigned waves, int64_t ntiles, unsigned big_tiles = BIG) {
         queue = q;
         n_waves = waves;
