@@ -398,7 +398,9 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_stats(const float2 *__r
             }
         }
         fetch(b + stride);
+#ifndef ABL_NO_FFT      // experiment (timing only): the row transform left out
         forward(v, tw, lds[wave], lane);
+#endif
         float pm = 0.f, pl = 0.f, pu = 0.f;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
@@ -442,7 +444,11 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_bwd(const float2 *__res
             x[m] = {t.x, t.y};
             v[m] = x[m];
         }
+#ifdef ABL_NO_FFT
+        if (false) {
+#else
         if (need_fft) {
+#endif
             forward(v, tw, lds[wave], lane);
             // Y = conj(w X), then the transposed transform: IDFT_unnormalised(w X) = conj(F conj(w X))
 #pragma unroll
