@@ -459,7 +459,8 @@ extern "C" int dpd_critic_backward(const float *x, const float *cond, int64_t N,
     DPD_REQUIRE(((x && cond) || N == 0) && wb && (grads || gx || N == 0), DPD_ERR_INVALID_ARG, "critic_backward: null pointer");
     DPD_REQUIRE(!grads || (ws && ws_bytes >= dpd_workspace_bytes(0)), DPD_ERR_WORKSPACE, "critic_backward: workspace too small");
     hipStream_t st = as_stream(stream);
-    if (score_sum) DPD_HIP(hipMemsetAsync(score_sum, 0, sizeof(float), st));
+    // (with weight gradients the MFMA family writes the sum from its slab reduction: nothing to clear)
+    if (score_sum && !(N > 0 && grads && critic_use_mfma(N))) DPD_HIP(hipMemsetAsync(score_sum, 0, sizeof(float), st));
     if (N <= 0) {
         if (grads) DPD_HIP(hipMemsetAsync(grads, 0, C_NP * sizeof(float), st));
         return DPD_OK;
@@ -504,12 +505,13 @@ extern "C" int dpd_critic_gp(const float *real, const float *fake, const float *
     const size_t need = slab_bytes + (size_t)N * (8 + 16) + (size_t)B * 4 + 256;
     DPD_REQUIRE(ws && ws_bytes >= need, DPD_ERR_WORKSPACE, "critic_gp: workspace of %zu bytes needed, %zu given", need, ws_bytes);
     hipStream_t st = as_stream(stream);
-    DPD_HIP(hipMemsetAsync(gp, 0, sizeof(float), st));
+    const bool mfma_family = N > 0 && critic_use_mfma(N) && (L == 1 || (L & 15) == 0);
+    if (!mfma_family) DPD_HIP(hipMemsetAsync(gp, 0, sizeof(float), st));      // (the MFMA family writes gp, it does not add to it)
     if (N == 0) {
         DPD_HIP(hipMemsetAsync(grads, 0, C_NP * sizeof(float), st));
         return DPD_OK;
     }
-    if (critic_use_mfma(N) && (L == 1 || (L & 15) == 0)) {
+    if (mfma_family) {
         DPD_REQUIRE(ws_bytes >= critic_mfma_gp_ws_bytes(B, L), DPD_ERR_WORKSPACE, "critic_gp: workspace too small");
         return critic_mfma_gp(real, fake, cond, alpha, B, L, wb, slope, gp, rownorm, grads, ws, st);
     }

@@ -126,8 +126,9 @@ class CriticUpdate:
         self.wb, self.uv, self.sigma = torch.empty(3, n, **f), torch.empty(3, 229, **f), torch.empty(3, 4, **f)
         self.gwb, self.gpar = torch.empty(3, n, **f), torch.empty(3, n, **f)
         self.total = torch.zeros(n, **f)
-        self.sums = torch.zeros(4, **f)                # sum D(real), sum D(fake), gradient penalty, unused
+        self.sums = torch.zeros(4, **f)                # sum D(real), sum D(fake), gradient penalty, unused (stays 0)
         self.rownorm = None
+        self.coef, self.coef_n = None, None
 
     @staticmethod
     def supported(disc) -> bool:
@@ -159,7 +160,6 @@ class CriticUpdate:
         vs = _ptr_array([lin.weight_v for lin in self.layers])
         eps, slope, power = float(self.layers[0].eps), float(disc.leaky_slope), int(disc.training)
         _, wsp, wsn = L.workspace(dev, N)
-        self.sums.zero_()
         if alpha is None:
             alpha = torch.rand(B, 1, device=dev)
         if self.rownorm is None or self.rownorm.numel() != B:
@@ -185,9 +185,12 @@ class CriticUpdate:
         self._bind_grads()
         dp.sum_(self.total)
         self.opt.step()
-        s = self.sums
-        # this rank's share of the critic loss (the caller sums the shares of all ranks, once per step)
-        return ((s[1] - s[0]) / N + self.gp_weight * s[2]) / dp.world
+        # this rank's share of the critic loss, (sum D(fake) - sum D(real)) / N + gp_weight * gp, over the number of ranks
+        # (the caller sums the shares of all ranks, once per step): one dot product with the three sums the calls left
+        if self.coef is None or self.coef_n != (N, dp.world):
+            self.coef = torch.tensor([-1.0 / N, 1.0 / N, self.gp_weight, 0.0], dtype=torch.float32, device=dev) / dp.world
+            self.coef_n = (N, dp.world)
+        return torch.dot(self.sums, self.coef)
 
 
 class Stage2Step:
