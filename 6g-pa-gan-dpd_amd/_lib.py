@@ -24,6 +24,7 @@ PROTOTYPES = {
     "dpd_tap_assembly": [c_p, c_l, c_l, c_p, c_p],
     "dpd_gen_prepare_weights": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "dpd_gen_absmax_pass": [c_i, c_p, c_l, c_l, c_i, c_p, c_f, c_p, c_p, c_i, c_p],
+    "dpd_gen_uses_mfma": [c_l, c_l, c_i, c_i],
     "dpd_gen_quantize_output": [c_p, c_l, c_p, c_p],
     "dpd_gen_forward": [c_p, c_l, c_l, c_i, c_p, c_f, c_i, c_p, c_p, c_i, c_p],
     "dpd_gen_backward": [c_p, c_l, c_l, c_i, c_p, c_f, c_i, c_p, c_p, c_p, c_p, c_p, c_sz, c_i, c_p],
@@ -35,6 +36,9 @@ PROTOTYPES = {
     "dpd_gen_pa_forward": [c_p, c_l, c_l, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p],
     "dpd_gen_pa_backward": [c_p, c_l, c_l, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_sz, c_p],
     "dpd_gen_pa_mse_step": [c_p, c_l, c_l, c_p, c_p, c_f, c_i, c_p, c_p, c_p, c_i, c_i, c_p, c_p, c_p, c_sz, c_p],
+    "dpd_impair_workspace_bytes": [c_l, c_l],
+    "dpd_augment_rows": [c_p, c_l, c_l, c_p, c_p, ctypes.c_uint64, c_p, c_p, c_sz, c_p],
+    "dpd_pa_add_noise": [c_p, c_l, c_l, c_p, c_f, c_p, c_p, ctypes.c_uint64, c_p, c_p, c_sz, c_p],
     "dpd_critic_sn_forward": [c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p],
     "dpd_critic_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p],
     "dpd_critic_forward": [c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p],
@@ -60,7 +64,7 @@ PROTOTYPES = {
     "dpd_last_error": [],
     "dpd_version": [],
 }
-_RESTYPES = {"dpd_workspace_bytes": c_sz, "dpd_q88_matrix_image_bytes": c_sz, "dpd_last_error": ctypes.c_char_p}
+_RESTYPES = {"dpd_workspace_bytes": c_sz, "dpd_impair_workspace_bytes": c_sz, "dpd_q88_matrix_image_bytes": c_sz, "dpd_last_error": ctypes.c_char_p}
 
 
 def lib():

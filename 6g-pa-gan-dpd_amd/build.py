@@ -6,8 +6,13 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libdpd_hip.so")
+ASAN_LIB = os.environ.get("DPD_ASAN_OUT", "/tmp/libdpd_hip_asan.so")   # the sanitizer build never replaces the product library
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 EXTRA = os.environ.get("DPD_EXTRA_FLAGS", "").split()   # experiments only, e.g. -DBWD_WAVES_PER_SIMD=1
+# DPD_ASAN=1: AddressSanitizer on the HOST side of the library only (argument validation, workspace arithmetic,
+# launch set-up), for the CPU-side tests; the device code is built as always.  Run the tests of such a build with
+# LD_PRELOAD=$(hipcc -print-file-name=libclang_rt.asan-x86_64.so) and DPD_HIP_LIBRARY=<the library>.
+ASAN = os.environ.get("DPD_ASAN", "") not in ("", "0")
 # -ffp-contract=off: the reference computes I*I + Q*Q and friends with separate roundings; fused
 # multiply-adds are written explicitly where they are wanted.
 # -amdgpu-mfma-vgpr-form: MFMA results land in VGPRs; the kernels consume them on the VALU right
@@ -29,15 +34,20 @@ def needs_build():
 
 
 def build(force=False, verbose=True, jobs=8):
+    if ASAN:
+        return _build(ASAN_LIB, os.path.join(os.path.dirname(ASAN_LIB), "dpd_hip_asan_obj"), verbose, jobs)
     if not force and not needs_build():
         return LIB
-    objdir = os.path.join(HERE, "build")
+    return _build(LIB, os.path.join(HERE, "build"), verbose, jobs)
+
+
+def _build(lib_path, objdir, verbose, jobs):
     os.makedirs(objdir, exist_ok=True)
     procs, objs = [], []
     for src in sources():
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
-        cmd = [HIPCC] + FLAGS + EXTRA + ["-c", src, "-o", obj]
+        cmd = [HIPCC] + FLAGS + EXTRA + (["-Xarch_host", "-fsanitize=address", "-g"] if ASAN else []) + ["-c", src, "-o", obj]
         if src.endswith(".cpp"):
             cmd.insert(1, "-x"); cmd.insert(2, "hip")
         if verbose:
@@ -50,11 +60,11 @@ def build(force=False, verbose=True, jobs=8):
     for s, p in procs:
         if p.wait() != 0:
             raise RuntimeError(f"hipcc failed on {s}")
-    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB]
+    cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC"] + (["-fsanitize=address", "-fno-gpu-sanitize"] if ASAN else []) + objs + ["-o", lib_path]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)
-    return LIB
+    return lib_path
 
 
 if __name__ == "__main__":

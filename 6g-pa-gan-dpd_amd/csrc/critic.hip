@@ -22,9 +22,10 @@ int critic_mfma_forward(const float *x, const float *cond, int64_t N, const floa
                         float *score_sum, hipStream_t st);
 int critic_mfma_backward(const float *x, const float *cond, int64_t N, const float *wb, float slope, const float *gscore,
                          float gconst, float *grads, float *gx, float *score_sum, float *ws, hipStream_t st);
-size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L);
+size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L, size_t ws_bytes);
 int critic_mfma_gp(const float *real, const float *fake, const float *cond, const float *alpha, int64_t B, int64_t L,
-                   const float *wb, float slope, float *gp, float *rownorm, float *grads, void *ws, hipStream_t st);
+                   const float *wb, float slope, float *gp, float *rownorm, float *grads, void *ws, size_t ws_bytes,
+                   hipStream_t st);
 
 // kernel family: 0 = by size (MFMA from 1024 samples), 1 = VALU, 2 = MFMA
 static int g_critic_impl = 0;
@@ -512,8 +513,8 @@ extern "C" int dpd_critic_gp(const float *real, const float *fake, const float *
         return DPD_OK;
     }
     if (mfma_family) {
-        DPD_REQUIRE(ws_bytes >= critic_mfma_gp_ws_bytes(B, L), DPD_ERR_WORKSPACE, "critic_gp: workspace too small");
-        return critic_mfma_gp(real, fake, cond, alpha, B, L, wb, slope, gp, rownorm, grads, ws, st);
+        DPD_REQUIRE(ws_bytes >= critic_mfma_gp_ws_bytes(B, L, ws_bytes), DPD_ERR_WORKSPACE, "critic_gp: workspace too small");
+        return critic_mfma_gp(real, fake, cond, alpha, B, L, wb, slope, gp, rownorm, grads, ws, ws_bytes, st);
     }
     char *base = reinterpret_cast<char *>(ws);
     float *slab = reinterpret_cast<float *>(base);

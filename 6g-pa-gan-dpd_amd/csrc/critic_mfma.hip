@@ -2110,10 +2110,13 @@ int critic_mfma_backward(const float *x, const float *cond, int64_t N, const flo
 //            tile counters of pass A and pass C (inside the 1024 spare bytes)
 int g_gp_fused = 1;               // dpd_set_option("gp_fused", 0 / 1): the one-pass form where the shape allows it
 
-// rows of a multiple of 16 tiles: no hand-out unit crosses a row (units of 32 tiles only if rows are a multiple of 32)
-static bool gp_fused_shape(int64_t L) {
+static size_t gp_fused_ws_bytes(int64_t B, int64_t L);
+// rows of a multiple of 16 tiles: no hand-out unit crosses a row (units of 32 tiles only if rows are a multiple of 32).
+// The per-unit partials of short rows (units of 16 tiles: 48 bytes per sample) can need more than the documented
+// workspace, dpd_workspace_bytes(B * L): such a call takes the three-pass form, which always fits.
+static bool gp_fused_shape(int64_t B, int64_t L, size_t ws_bytes) {
 #if CRITIC_OUTER_BF16
-    return g_gp_fused && L >= 256 && (L & 255) == 0;
+    return g_gp_fused && L >= 256 && (L & 255) == 0 && gp_fused_ws_bytes(B, L) <= ws_bytes;
 #else
     return false;
 #endif
@@ -2134,14 +2137,16 @@ static size_t gp_fused_ws_bytes(int64_t B, int64_t L) {
 #endif
     return (size_t)512 * C_SLAB * 4 + (size_t)n_units * 48 * 64 * 4 + (size_t)nt * 4 + (size_t)B * 8 + (size_t)256 * C_SLAB * 4 + 1024;
 }
-size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L) {
+// what the call will use of a workspace of ws_bytes (the one-pass form only if it fits)
+size_t critic_mfma_gp_ws_bytes(int64_t B, int64_t L, size_t ws_bytes) {
     const int64_t N = B * L, nt = (N + 15) >> 4;
     const size_t three_pass = (size_t)512 * C_SLAB * 4 + (size_t)nt * 64 * 4 + (size_t)N * 8 + (size_t)nt * 4 + (size_t)B * 8 + 1024;
-    return gp_fused_shape(L) ? gp_fused_ws_bytes(B, L) : three_pass;
+    return gp_fused_shape(B, L, ws_bytes) ? gp_fused_ws_bytes(B, L) : three_pass;
 }
 
 int critic_mfma_gp(const float *real, const float *fake, const float *cond, const float *alpha, int64_t B, int64_t L,
-                   const float *wb, float slope, float *gp, float *rownorm, float *grads, void *ws, hipStream_t st) {
+                   const float *wb, float slope, float *gp, float *rownorm, float *grads, void *ws, size_t ws_bytes,
+                   hipStream_t st) {
     const int64_t N = B * L, nt = (N + 15) >> 4;
     char *base = reinterpret_cast<char *>(ws);
     float *slab = reinterpret_cast<float *>(base);
@@ -2157,7 +2162,7 @@ int critic_mfma_gp(const float *real, const float *fake, const float *cond, cons
     if (rc) return rc;
     unsigned *queue;
 #if CRITIC_OUTER_BF16
-    if (gp_fused_shape(L)) {
+    if (gp_fused_shape(B, L, ws_bytes)) {
         unsigned n_big, n_units;
         gp_units(nt, L, &n_big, &n_units);
         size_t o = (size_t)512 * C_SLAB * 4;

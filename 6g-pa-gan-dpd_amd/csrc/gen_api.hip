@@ -73,6 +73,13 @@ extern "C" int dpd_gen_absmax_pass(int stage, const float *x, int64_t B, int64_t
     return forward_dispatch(p, stage, out, impl, st);
 }
 
+extern "C" int dpd_gen_uses_mfma(int64_t B, int64_t S, int pre_assembled, int impl) {
+    GenProblem p;
+    p.pre = pre_assembled != 0;
+    p.N = p.pre ? B : B * (S - DPD_GEN_MEMORY);
+    return use_mfma(p, impl) ? 1 : 0;
+}
+
 extern "C" int dpd_gen_quantize_output(float *out, int64_t n, const float *absmax, void *stream) {
     DPD_REQUIRE((out || n == 0) && absmax && n >= 0, DPD_ERR_INVALID_ARG, "quantize_output: bad argument");
     if (n == 0) return DPD_OK;

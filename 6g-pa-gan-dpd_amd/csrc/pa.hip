@@ -92,9 +92,11 @@ __global__ __launch_bounds__(256) void k_pa_bwd(const float2 *__restrict__ x, in
     }
 }
 
-// gy = (y - t) * scale element by element, and one partial sum of (y - t)^2 per workgroup (fixed order inside)
-__global__ __launch_bounds__(256) void k_mse_grad(const float *__restrict__ y, const float *__restrict__ t, int64_t n,
-                                                  float scale, float *__restrict__ gy, double *__restrict__ part) {
+// gy = (y - t) * scale element by element, and one partial sum of (y - t)^2 per workgroup (fixed order inside).
+// gy may be y itself (the chain's fallback path overwrites the PA output with its gradient: every element is read
+// and then written by the same thread), so neither of the two is declared restrict.
+__global__ __launch_bounds__(256) void k_mse_grad(const float *y, const float *__restrict__ t, int64_t n,
+                                                  float scale, float *gy, double *__restrict__ part) {
     __shared__ double red[4];
     double acc = 0.0;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {

@@ -814,6 +814,15 @@ extern "C" int dpd_spectral_stats(const float *pred, const float *target, int64_
                 "spectral_stats: row length %lld is neither a power of two in 2..4096 nor within the direct-DFT limit of 8192", (long long)L);
     if (B <= 0) return DPD_OK;
     if (band && !pow2) {
+        // the row sits in dynamic LDS next to the kernel's static words: the longest rows need more than the
+        // 64 KiB a launch gets without the attribute (set once per device)
+        static PerDeviceOnce attr_once;
+        int attr_dev;
+        if (attr_once.first_use(&attr_dev)) {
+            DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_spectral_stats_dft),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(8192 * sizeof(float2))));
+            attr_once.mark(attr_dev);
+        }
         hipLaunchKernelGGL(k_spectral_stats_dft, dim3((unsigned)B), dim3(TPB), (size_t)L * sizeof(float2), as_stream(stream),
                            reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), L, band, stats);
         DPD_LAUNCH_CHECK();

@@ -3,9 +3,9 @@ Discriminator :45-136, compute_gradient_penalty :139-191, WassersteinLoss :194-2
 create_discriminator :270-281) on top of libdpd_hip.so.
 
 The critic MLP, its backward and the gradient penalty (with its double backward) run in the HIP
-kernels of csrc/critic.hip.  Spectral normalisation (one power iteration per training-mode
-forward on 64x4 .. 1x16 matrices) stays in torch on the device; its result W / sigma is what the
-kernels consume, and autograd carries the kernels' dL/d(W/sigma) back to `weight_orig`.
+kernels of csrc/critic.hip and csrc/critic_mfma.hip.  Spectral normalisation (one power iteration per
+training-mode forward on 64x4 .. 1x16 matrices, sigma, W / sigma and the backward to `weight_orig`) is one
+launch each way in csrc/critic_sn.hip; nothing of the critic is computed by torch ops.
 State-dict keys match the reference: features.{0,2,4}.linear.{bias,weight_orig,weight_u,weight_v}
 and output.linear.*.
 """
@@ -35,17 +35,6 @@ class _SNLinearCore(nn.Module):
             v = F.normalize(lin.weight.new_empty(in_features).normal_(0, 1), dim=0, eps=eps)
         self.register_buffer("weight_u", u)
         self.register_buffer("weight_v", v)
-
-    def normalized_weight(self, power_iteration: bool) -> torch.Tensor:
-        w = self.weight_orig
-        u, v = self.weight_u, self.weight_v
-        if power_iteration:
-            with torch.no_grad():
-                v = F.normalize(torch.mv(w.t(), u), dim=0, eps=self.eps, out=v)
-                u = F.normalize(torch.mv(w, v), dim=0, eps=self.eps, out=u)
-                u, v = u.clone(), v.clone()
-        sigma = torch.dot(u, torch.mv(w, v))
-        return w / sigma
 
 
 def _ptr_array(tensors):
@@ -220,16 +209,18 @@ class Discriminator(nn.Module):
         if self.input_dim != 4 or list(self.hidden_dims) != [64, 32, 16]:
             raise NotImplementedError("the HIP critic is built for 4 -> 64 -> 32 -> 16 -> 1 (the reference default)")
         layers = list(self._layers())
-        if all(isinstance(lin, _SNLinearCore) for lin in layers) and layers[0].weight_orig.is_cuda:
+        if all(isinstance(lin, _SNLinearCore) for lin in layers):
+            L.need_gpu(layers[0].weight_orig)       # the spectral normalisation is a HIP kernel: no CPU path
             args = []
             for lin in layers:
                 args += [lin.weight_orig, lin.bias]
             return _SNFlatFn.apply(self.training, layers[0].eps, [lin.weight_u for lin in layers],
                                    [lin.weight_v for lin in layers], *args)
+        # use_spectral_norm=False: plain Linear layers, whose parameters are only packed into the flat operand
+        L.need_gpu(layers[0].weight)
         parts = []
         for lin in layers:
-            w = lin.normalized_weight(self.training) if isinstance(lin, _SNLinearCore) else lin.weight
-            parts += [w.reshape(-1), lin.bias]
+            parts += [lin.weight.reshape(-1), lin.bias]
         return torch.cat(parts)
 
     def mean_score(self, x: torch.Tensor, condition: torch.Tensor) -> torch.Tensor:

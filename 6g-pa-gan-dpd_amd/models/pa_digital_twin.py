@@ -117,15 +117,29 @@ class PADigitalTwin(nn.Module):
         self.pa_model.coeffs_real.copy_(re)
         self.pa_model.coeffs_imag.copy_(im)
 
-    def add_noise(self, x: torch.Tensor) -> torch.Tensor:
-        signal_power = (x ** 2).mean()
-        noise_std = torch.sqrt(signal_power * (10 ** (self.noise_floor_db / 10)))
-        awgn = torch.randn_like(x) * noise_std
-        if self.phase_noise_deg > 0:
-            pn = torch.randn(x.shape[0], x.shape[1], device=x.device) * (self.phase_noise_deg * np.pi / 180)
-            xc = torch.view_as_complex(x.contiguous()) * torch.polar(torch.ones_like(pn), pn)
-            x = torch.view_as_real(xc)
-        return x + awgn
+    def add_noise(self, x: torch.Tensor, draws: Optional[dict] = None, seed: Optional[int] = None) -> torch.Tensor:
+        """AWGN at noise_floor_db relative to the power of the whole tensor plus per-sample phase noise
+        (models/pa_digital_twin.py:280-309), one kernel pass.  `draws` = dict(awgn [B, S, 2], phase [B, S]) of standard
+        normals fixes the random numbers (the reference takes them from torch.randn_like / torch.randn); otherwise they
+        come from the kernel's counter-based generator, keyed by `seed` (default: a fresh seed from torch's generator).
+        Evaluation-time impairment: no gradient flows through it (the reference's scripts use it for validation only)."""
+        L.need_gpu(x)
+        xc = L.as_f32(x)
+        n = xc.numel() // 2
+        params = torch.tensor([[10.0 ** (self.noise_floor_db / 10.0), 1.0, 1.0, 0.0, 1.0, 0.0, 0.0, 0.0]],
+                              dtype=torch.float32, device=xc.device)
+        pn_rad = float(self.phase_noise_deg * np.pi / 180) if self.phase_noise_deg > 0 else 0.0
+        awgn = pn = None
+        if draws is not None:
+            awgn, pn = L.as_f32(draws["awgn"]).reshape(-1), L.as_f32(draws["phase"]).reshape(-1)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+        nbytes = int(L.lib().dpd_impair_workspace_bytes(1, n))
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=xc.device)
+        out = torch.empty_like(xc)
+        L.call("dpd_pa_add_noise", L.fptr(xc), 1, n, L.fptr(params), pn_rad, L.fptr(awgn), L.fptr(pn),
+               int(seed) & 0xFFFFFFFFFFFFFFFF, L.fptr(out), L.c_p(ws.data_ptr()), L.c_sz(ws.numel()), L.stream())
+        return out
 
     def forward(self, x: torch.Tensor, add_noise: bool = True, temp_state: Optional[str] = None) -> torch.Tensor:
         if temp_state is not None:

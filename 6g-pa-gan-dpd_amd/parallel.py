@@ -12,6 +12,7 @@ Exact-global semantics (results equal to one process on the concatenated batch):
     all-reduced per-row sums via GlobalSum, whose backward is the identity;
   * every loss term is then a function of global sums, so gradients are all-reduced with SUM.
 """
+import os
 from typing import Iterable, List, Optional
 
 import torch
@@ -23,7 +24,7 @@ def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
     one-GPU rehearsal of the multi-rank path) a device tensor is reduced through a host copy: gloo's own handling of
     device tensors is not dependable on ROCm builds (observed: two ranks on one GPU stall inside all_reduce after a
     few dozen calls), and the payloads here are a few kilobytes."""
-    if t.is_cuda and dist.get_backend(group) == "gloo":
+    if t.is_cuda and dist.get_backend(group) == "gloo" and os.environ.get("DPD_GLOO_DEVICE_TENSORS") != "1":
         h = t.detach().cpu()
         dist.all_reduce(h, op=op, group=group)
         t.copy_(h)

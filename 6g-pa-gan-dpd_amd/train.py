@@ -232,10 +232,17 @@ def main(argv=None) -> Dict[str, float]:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # DPD_BENCH_REHEARSAL=1: every rank on GPU 0 with the gloo backend -- runs the N > 1 code path on a one-GPU box
+    rehearsal = os.environ.get("DPD_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 and not torch.distributed.is_initialized():
-        torch.distributed.init_process_group("nccl", device_id=device)
+        if rehearsal:
+            torch.distributed.init_process_group("gloo")
+        else:
+            torch.distributed.init_process_group("nccl", device_id=device)
     dp = DataParallel()
 
     if args.data_dir:
@@ -288,9 +295,12 @@ def main(argv=None) -> Dict[str, float]:
             else:
                 info = stage2(xb, tb, xb[:, 5:, :].contiguous())
                 logs.append(info["g_total"].detach().reshape(1))
-        for s in (g_sch, d_sch):
-            if s is not None:
-                s.step()
+        # the critic's schedule advances only in epochs in which the critic was updated (as the two-stage loop of
+        # training_colab.ipynb code cell 14 does: scheduler_D.step() is skipped while pre-training)
+        if g_sch is not None:
+            g_sch.step()
+        if d_sch is not None and epoch >= s1_epochs:
+            d_sch.step()
         metrics = validate(gen, sl, x_va, t_va, batch)
         metrics["train_loss"] = float(torch.cat(logs).mean().item()) if logs else float("nan")
         metrics["stage"] = 1 if epoch < s1_epochs else 2

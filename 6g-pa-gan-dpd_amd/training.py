@@ -65,9 +65,10 @@ class Stage1Step:
         L.call("dpd_gen_prepare_weights", *(L.fptr(p.detach()) for p in self.params), int(qat), L.fptr(self.wq),
                L.fptr(self.absmax), st)
         if qat:
-            # the last pass writes the generator output unless the MFMA family runs it (IQ input of >= 4096
-            # samples): the step has no use for that output, so it is not written where it can be left out
-            mfma = self.impl == L.IMPL_MFMA or (self.impl == L.IMPL_AUTO and B * (S - 5) >= 4096)
+            # the last pass writes the generator output unless the MFMA family runs it (the library says which
+            # family takes this shape): the step has no use for that output, so it is not written where it can
+            # be left out
+            mfma = bool(L.lib().dpd_gen_uses_mfma(B, S, 0, self.impl))
             outp = L.fptr(None)
             if not mfma:
                 if self.scratch_out is None or self.scratch_out.shape[0] != B or self.scratch_out.shape[1] != S - 5:

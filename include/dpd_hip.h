@@ -94,6 +94,11 @@ int dpd_gen_prepare_weights(const float *w1, const float *b1, const float *w2, c
 int dpd_gen_absmax_pass(int stage, const float *x, int64_t B, int64_t S, int pre_assembled,
                         const float *wq, float slope, float *absmax, float *out, int impl, void *stream);
 
+/* 1 if a generator call of this shape runs on the MFMA kernels, 0 if on the VALU kernels (the rule behind
+ * DPD_IMPL_AUTO; with it a caller knows whether stage 3 of dpd_gen_absmax_pass may be given out == NULL).  Part of
+ * the dispatch of TDNNGeneratorQAT.forward (models/tdnn_generator.py:412-456), which has no such choice. */
+int dpd_gen_uses_mfma(int64_t B, int64_t S, int pre_assembled, int impl);
+
 /* Final step of the QAT forward: out = fake_quant(out, absmax[3]) in place over n floats. */
 int dpd_gen_quantize_output(float *out, int64_t n, const float *absmax, void *stream);
 
@@ -178,6 +183,31 @@ int dpd_gen_pa_backward(const float *iq, int64_t B, int64_t S, const float *wq, 
 int dpd_gen_pa_mse_step(const float *iq, int64_t B, int64_t S, const float *target, const float *wq, float slope,
                         int qat, const float *absmax, const float *coef_re, const float *coef_im, int K, int M,
                         float *grads, float *loss, void *ws, size_t ws_bytes, void *stream);
+
+/* ---------------------------------------------------------------- signal impairments ---- */
+
+/* Bytes of scratch for the two calls below on [B, S, 2] rows. */
+size_t dpd_impair_workspace_bytes(int64_t B, int64_t S);
+
+/* Training-time augmentation of IQ rows x [B,S,2] -> out [B,S,2] (may be x): `augment_signal` of the reference's
+ * notebook (training_colab.ipynb, data-loading cell) with one set of draws per row.  params [B,8] per row:
+ * 0 noise_rel and 1 noise_mul (noise std = sqrt(mean(row^2) * noise_rel) * noise_mul; the notebook's
+ * 1 / 10^(snr_db/10) and `strength`; noise_mul = 0: no noise), 2, 3 cos / sin of the phase offset, 4 gain,
+ * 5 thermal gain shift (0: no thermal stage), 6 thermal phase shift in rad, 7 AM-AM compression: the stages run in
+ * the notebook's order (noise, phase, gain, thermal with gain_shift * (1 - 0.1 |v|^2 compression)).
+ * noise [B,S,2]: standard normal draws, or NULL: drawn in the kernel from a counter-based generator keyed by
+ * `seed` (sample index as the counter; same seed, same draws). */
+int dpd_augment_rows(const float *x, int64_t B, int64_t S, const float *params, const float *noise, uint64_t seed,
+                     float *out, void *ws, size_t ws_bytes, void *stream);
+
+/* PADigitalTwin.add_noise (models/pa_digital_twin.py:280-309) on x [B,S,2] -> out: every sample rotated by
+ * phase_noise_rad * (a standard normal draw), plus white noise of std sqrt(mean(row^2) * params[b,0]) * params[b,1]
+ * (params [B,8] as above, entries 2..7 unused).  The reference takes the power over the whole tensor: call with
+ * B = 1 and S = all samples for that.  noise [B,S,2] and phase_noise [B,S]: the draws, or both NULL: drawn in the
+ * kernel from `seed`. */
+int dpd_pa_add_noise(const float *x, int64_t B, int64_t S, const float *params, float phase_noise_rad,
+                     const float *noise, const float *phase_noise, uint64_t seed, float *out, void *ws,
+                     size_t ws_bytes, void *stream);
 
 /* ---------------------------------------------------------------- critic ---------------- */
 

@@ -77,3 +77,66 @@ def test_pa_noise_statistics():
     assert torch.allclose(yc.abs(), xc.abs(), rtol=1e-5, atol=1e-7)          # a pure rotation
     out = pa(x, add_noise=True)
     assert out.shape == (64, 1025, 2)
+
+
+def test_augment_signal_matches_notebook_with_recorded_draws():
+    """dpd_augment_rows through data.augment_signal against the notebook's own augment_signal run on the same random
+    numbers (fixture g14: every augment_type, the three thermal outcomes, two strengths), and against the oracle on
+    another length.  Tolerance: fp32 rounding of a different but equivalent operation order (rotation by the thermal
+    phase shift instead of atan2 / cos / sin), 2e-6 of the signal's peak."""
+    from dpd_amd.data import augment_signal
+    from oracle import augment as oa
+    g = load_golden("g14_augment")
+    sig = torch.from_numpy(g["signal"])
+    peak = float(sig.abs().max())
+    worst = 0.0
+    for i in range(int(g["n_cases"])):
+        kind, strength = str(g[f"c{i}_kind"]), float(g[f"c{i}_strength"])
+        snr, phase, gain, thermal = (float(v) for v in g[f"c{i}_scalars"])
+        draws = dict(snr=snr, phase=phase, gain=gain, thermal=thermal, noise=torch.from_numpy(g[f"c{i}_noise"]).to(DEV))
+        got = augment_signal(sig.to(DEV), kind, strength, draws=draws).cpu()
+        err = float((got - torch.from_numpy(g[f"c{i}_out"])).abs().max())
+        worst = max(worst, err)
+        assert err <= 2e-6 * peak, (i, kind, err)
+    print(f"augment_signal vs notebook: worst abs error {worst:.3e} (signal peak {peak:.3f})")
+    torch.manual_seed(3)
+    s2 = torch.randn(777, 2) * 0.4
+    nz = torch.randn(777, 2)
+    for kind, th in (("all", 0.1), ("all", 0.9), ("thermal", 0.5), ("noise", 0.0)):
+        want = oa.augment_signal(s2, kind, 0.2, -0.7, nz, 0.8, 0.1, th)
+        got = augment_signal(s2.to(DEV), kind, 0.2, draws=dict(snr=-0.7, phase=0.8, gain=0.1, thermal=th, noise=nz.to(DEV))).cpu()
+        assert float((got - want).abs().max()) <= 2e-6 * float(s2.abs().max())
+    with pytest.raises(ValueError):
+        augment_signal(sig.to(DEV), "fade", 0.1)
+
+
+def test_pa_add_noise_matches_reference_with_recorded_draws():
+    """dpd_pa_add_noise against PADigitalTwin.add_noise of the reference run on the same normal draws (fixture g14)."""
+    from dpd_amd.models import PADigitalTwin
+    g = load_golden("g14_augment")
+    pa = PADigitalTwin(noise_floor_db=float(g["pa_noise_floor_db"]), phase_noise_deg=float(g["pa_phase_noise_deg"])).to(DEV)
+    x = torch.from_numpy(g["pa_x"]).to(DEV)
+    got = pa.add_noise(x, draws=dict(awgn=torch.from_numpy(g["pa_awgn"]).to(DEV), phase=torch.from_numpy(g["pa_phase"]).to(DEV))).cpu()
+    err = float((got - torch.from_numpy(g["pa_out"])).abs().max())
+    print(f"add_noise vs reference: worst abs error {err:.3e} (signal peak {float(x.abs().max()):.2f})")
+    assert err <= 2e-6 * float(x.abs().max())
+
+
+def test_kernel_generator_draws_are_standard_normal():
+    """The counter-based generator inside the impairment kernels: moments of 2^21 deviates per component, independence
+    of the two components, reproducible per seed and different between seeds."""
+    from dpd_amd.models import PADigitalTwin
+    pa = PADigitalTwin(noise_floor_db=0.0, phase_noise_deg=0.0).to(DEV)     # noise power == signal power, no rotation
+    x = torch.full((1, 1 << 21, 2), 0.5, device=DEV)                        # mean(x^2) = 0.25: noise std 0.5
+    z = (pa.add_noise(x, seed=11) - x) / 0.5
+    assert torch.equal(z, (pa.add_noise(x, seed=11) - x) / 0.5)
+    assert not torch.equal(z, (pa.add_noise(x, seed=12) - x) / 0.5)
+    zi, zq = z[0, :, 0].double(), z[0, :, 1].double()
+    n = zi.numel()
+    for v in (zi, zq):
+        assert abs(float(v.mean())) < 4 / n ** 0.5
+        assert abs(float(v.var()) - 1) < 4 * (2 / n) ** 0.5
+        assert abs(float((v ** 4).mean()) - 3) < 0.05
+        assert abs(float((v ** 3).mean())) < 0.02
+    assert abs(float((zi * zq).mean())) < 4 / n ** 0.5
+    assert abs(float((zi[1:] * zi[:-1]).mean())) < 4 / n ** 0.5               # no correlation between neighbours

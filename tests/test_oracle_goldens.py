@@ -291,3 +291,23 @@ def test_q88_bit_exact():
     for k in ("feat_q", "z1", "h1", "z2", "h2", "z3", "lut_idx"):
         assert np.array_equal(mid[k].astype(np.int64), g[k].astype(np.int64)), k
     assert np.array_equal(out, g["out_i16"])
+
+
+def test_augmentation_and_pa_noise_with_recorded_draws():
+    """oracle/augment.py against what the notebook's own augment_signal and PADigitalTwin.add_noise produced from the
+    same random numbers (fixture g14; both are the same torch ops in the same order: equal to the last bits)."""
+    from oracle import augment as oa
+    g = load_golden("g14_augment")
+    sig = torch.from_numpy(g["signal"])
+    kinds = set()
+    for i in range(int(g["n_cases"])):
+        kind, strength = str(g[f"c{i}_kind"]), float(g[f"c{i}_strength"])
+        snr, phase, gain, thermal = (float(v) for v in g[f"c{i}_scalars"])
+        out = oa.augment_signal(sig, kind, strength, snr, torch.from_numpy(g[f"c{i}_noise"]), phase, gain, thermal)
+        np.testing.assert_allclose(out.numpy(), g[f"c{i}_out"], rtol=1e-6, atol=1e-7)
+        kinds.add((kind, "cold" if thermal < 0.33 else ("normal" if thermal < 0.67 else "hot")))
+    assert {k for k, _ in kinds} == {"noise", "phase", "gain", "thermal", "all"}
+    assert {t for k, t in kinds if k == "all"} == {"cold", "normal", "hot"}
+    y = oa.pa_add_noise(torch.from_numpy(g["pa_x"]), torch.from_numpy(g["pa_awgn"]), torch.from_numpy(g["pa_phase"]),
+                        float(g["pa_noise_floor_db"]), float(g["pa_phase_noise_deg"]))
+    np.testing.assert_allclose(y.numpy(), g["pa_out"], rtol=1e-6, atol=1e-6)

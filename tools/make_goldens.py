@@ -623,11 +623,93 @@ def g13_q88_hex():
     save("g13_q88_hex", **arrays)
 
 
+# ----------------------------------------------------------------------------- g14
+def g14_augment():
+    """Augmentation and PA noise with recorded draws: the notebook's own `augment_signal` (training_colab.ipynb,
+    data-loading cell), taken out of the cell's text, and PADigitalTwin.add_noise, each run under a seed; the random
+    numbers they consumed are recorded by replaying the same sequence of generator calls under the same seed."""
+    import ast
+    import json
+    with open(os.path.join(REF, "training_colab.ipynb")) as f:
+        nb = json.load(f)
+    src = next("".join(c["source"]) for c in nb["cells"] if c["cell_type"] == "code" and "def augment_signal" in "".join(c["source"]))
+    start = src.index("def augment_signal(")
+    lines = src[start:].split("\n")
+    body = [lines[0]]
+    for ln in lines[1:]:
+        if ln.strip() and not ln.startswith((" ", "\t")):
+            break
+        body.append(ln)
+    ns = dict(torch=torch, np=np)
+    exec(compile(ast.parse("\n".join(body)), "training_colab.ipynb", "exec"), ns)
+    augment_signal = ns["augment_signal"]
+    sig = ofdm_rows(1, 2048 + 5, seed=77)[0].contiguous()            # [2053, 2]
+    arrays = dict(signal=npy(sig))
+    cases = []
+    # seeds picked so that the thermal draw of the 'thermal' / 'all' cases covers cold, unchanged and hot
+    for kind in ("noise", "phase", "gain"):
+        cases.append((kind, 0.1, 5))
+    seed = 0
+    want = {"cold": None, "normal": None, "hot": None}
+    while any(v is None for v in want.values()):
+        torch.manual_seed(seed)
+        t = torch.rand(1).item()
+        st = "cold" if t < 0.33 else ("normal" if t < 0.67 else "hot")
+        if want[st] is None:
+            want[st] = seed
+        seed += 1
+    for st, sd in want.items():
+        cases.append(("thermal", 0.1, sd))
+    want = {"cold": None, "normal": None, "hot": None}
+    seed = 100
+    while any(v is None for v in want.values()):
+        torch.manual_seed(seed)
+        torch.randn(1); torch.randn_like(sig); torch.rand(1); torch.rand(1)
+        t = torch.rand(1).item()
+        st = "cold" if t < 0.33 else ("normal" if t < 0.67 else "hot")
+        if want[st] is None:
+            want[st] = seed
+        seed += 1
+    for st, sd in want.items():
+        cases.append(("all", 0.3 if st == "hot" else 0.1, sd))
+    for i, (kind, strength, sd) in enumerate(cases):
+        torch.manual_seed(sd)
+        out = augment_signal(sig, augment_type=kind, strength=strength)
+        torch.manual_seed(sd)                                           # replay: the draws in the order the function takes them
+        d = dict(snr=0.0, phase=0.5, gain=0.5, thermal=0.5, noise=torch.zeros_like(sig))
+        if kind in ("noise", "all"):
+            d["snr"] = torch.randn(1).item()
+            d["noise"] = torch.randn_like(sig)
+        if kind in ("phase", "all"):
+            d["phase"] = torch.rand(1).item()
+        if kind in ("gain", "all"):
+            d["gain"] = torch.rand(1).item()
+        if kind in ("thermal", "all"):
+            d["thermal"] = torch.rand(1).item()
+        arrays[f"c{i}_kind"] = np.array(kind)
+        arrays[f"c{i}_strength"] = np.array(strength)
+        arrays[f"c{i}_scalars"] = np.array([d["snr"], d["phase"], d["gain"], d["thermal"]], dtype=np.float64)
+        arrays[f"c{i}_noise"] = npy(d["noise"])
+        arrays[f"c{i}_out"] = npy(out)
+    arrays["n_cases"] = np.array(len(cases))
+    # PADigitalTwin.add_noise: awgn = randn_like(x), then phase noise = randn(B, S, 1)
+    pa = PADigitalTwin()
+    x = ofdm_rows(3, 261, seed=78) * 20.0
+    torch.manual_seed(4242)
+    y = pa.add_noise(x)
+    torch.manual_seed(4242)
+    awgn = torch.randn_like(x)
+    pn = torch.randn(x.shape[0], x.shape[1], 1)
+    arrays.update(pa_x=npy(x), pa_awgn=npy(awgn), pa_phase=npy(pn.squeeze(-1)), pa_out=npy(y),
+                  pa_noise_floor_db=np.array(pa.noise_floor_db), pa_phase_noise_deg=np.array(pa.phase_noise_deg))
+    save("g14_augment", **arrays)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(1)
     for fn in (g1_taps, g2_float_gen, g3_qat_gen, g4_fixed_point, g5_pa, g6_critic, g7_wgan_gp, g8_spectral,
-               g9_csv_chain, g10_steps, g11_q88, g12_data, g13_q88_hex):
+               g9_csv_chain, g10_steps, g11_q88, g12_data, g13_q88_hex, g14_augment):
         if len(sys.argv) > 1 and fn.__name__ not in sys.argv[1:]:
             continue
         fn()
