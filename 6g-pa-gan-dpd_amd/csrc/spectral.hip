@@ -258,10 +258,16 @@ DEV void fft16(cpx (&v)[16]) {
 struct Twiddles {
     const float2 *t1, *t2;
 };
+// Residue (sample index mod 64) a lane holds after the loads.  8-byte loads: lane l holds x[64 m + l].  16-byte loads
+// (WIDE): lane l loads the sample pairs (128 m' + 2 l, + 1); one half-wave exchange per register then leaves lanes
+// 0..31 with residue 2 l (all sixteen m) and lanes 32..63 with residue 2 (l - 32) + 1 -- see exchange_halves.
+template <bool WIDE>
+DEV int residue_of(int lane) { return WIDE ? 2 * (lane & 31) + (lane >> 5) : lane; }
+template <bool WIDE>
 DEV void make_tw(float2 *t1, float2 *t2) {
     for (int i = threadIdx.x; i < 1024; i += ROWS_PER_BLOCK * 64) {
         float s, c;
-        sincospif(-2.0f * (float)((i & 63) * (i >> 6)) / 1024.0f, &s, &c);
+        sincospif(-2.0f * (float)(residue_of<WIDE>(i & 63) * (i >> 6)) / 1024.0f, &s, &c);
         t1[i] = make_float2(c, s);
     }
     for (int i = threadIdx.x; i < 64; i += ROWS_PER_BLOCK * 64) {
@@ -270,6 +276,17 @@ DEV void make_tw(float2 *t1, float2 *t2) {
         t2[i] = make_float2(c, s);
     }
     __syncthreads();
+}
+// WIDE loads: registers A (first sample of the pair) and B (second) of the two wave halves -> (even m, odd m) of this
+// lane's residue.  v_permlane32_swap exchanges the upper half of its first operand with the lower half of its second:
+// lanes 0..31 keep A and receive the upper half's A (same residue 2 l, next m); lanes 32..63 receive the lower half's
+// B and keep their own B (residue 2 l + 1).  The same call applied to (even m, odd m) is the way back.
+DEV void exchange_halves(float &a, float &b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    unsigned u0 = r[0], u1 = r[1];
+    asm volatile("" : "+v"(u0), "+v"(u1));   // keeps the two results of the swap apart (the compiler folds them otherwise)
+    a = __builtin_bit_cast(float, u0);
+    b = __builtin_bit_cast(float, u1);
 }
 DEV cpx tw1(const Twiddles &t, int k, int lane) {
     const float2 w = t.t1[64 * k + lane];
@@ -280,13 +297,14 @@ DEV cpx tw2(const Twiddles &t, int q, int lane) {
     return {w.x, w.y};
 }
 
-DEV void forward(cpx (&v)[16], const Twiddles &tw, float2 *buf, int lane) {
+// col: the residue this lane holds (residue_of; the twiddle table t1 is already in lane order)
+DEV void forward(cpx (&v)[16], const Twiddles &tw, float2 *buf, int lane, int col) {
     const int k1 = lane >> 2, a = lane & 3;
     fft16(v);
 #pragma unroll
     for (int k = 1; k < 16; ++k) v[k] = cmul(v[k], tw1(tw, k, lane));
 #pragma unroll
-    for (int k = 0; k < 16; ++k) buf[k * PITCH + lane] = make_float2(v[k].x, v[k].y);
+    for (int k = 0; k < 16; ++k) buf[k * PITCH + col] = make_float2(v[k].x, v[k].y);
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
@@ -313,7 +331,7 @@ DEV void forward(cpx (&v)[16], const Twiddles &tw, float2 *buf, int lane) {
 }
 
 // the same stages in reverse order: output layout -> input layout
-DEV void transposed(cpx (&v)[16], const Twiddles &tw, float2 *buf, int lane) {
+DEV void transposed(cpx (&v)[16], const Twiddles &tw, float2 *buf, int lane, int col) {
     const int k1 = lane >> 2, a = lane & 3;
 #pragma unroll
     for (int qi = 0; qi < 4; ++qi) fft4(v[4 * qi], v[4 * qi + 1], v[4 * qi + 2], v[4 * qi + 3]);
@@ -336,7 +354,7 @@ DEV void transposed(cpx (&v)[16], const Twiddles &tw, float2 *buf, int lane) {
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
-        const float2 t = buf[k * PITCH + lane];
+        const float2 t = buf[k * PITCH + col];
         v[k] = {t.x, t.y};
     }
     __builtin_amdgcn_wave_barrier();
@@ -361,27 +379,75 @@ DEV void band_bits(unsigned (&bits)[3], const uint8_t *__restrict__ band, int la
     }
 }
 
+// Waits for every load issued so far, once, in front of a loop that prefetches the next row: the compiler sets the wait at
+// the loop's head from BOTH ways into it, and on the way in from the prologue the prefetched loads are the youngest
+// operations, so without this it would wait there, in every iteration, for the iteration's own stores as well
+// (vmcnt counts stores, and a store's acknowledgement takes a memory round trip).  s_waitcnt vmcnt(0) alone.
+#define DRAIN_VMEM() __builtin_amdgcn_s_waitcnt(0x0F70)
+
+// A row as the loads deliver it: 16 sample slots per lane.  8-byte loads: slot m = x[64 m + lane].  16-byte loads (WIDE,
+// rows 16-byte aligned): slots 2 m', 2 m' + 1 = the pair x[128 m' + 2 lane], x[128 m' + 2 lane + 1] -- half the memory
+// instructions for the same bytes.  Everything that works sample by sample (error sums, the sign / difference terms of
+// the gradient, the stores) uses the slots as they are; only the transform needs the residue layout (to_residues).
+template <bool WIDE>
+struct RowIO {
+    static DEV void load(float2 (&r)[16], const float2 *__restrict__ row, int lane, bool live) {
+        if (WIDE) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float4 q = live ? reinterpret_cast<const float4 *>(row)[64 * m + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+                r[2 * m] = make_float2(q.x, q.y);
+                r[2 * m + 1] = make_float2(q.z, q.w);
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) r[m] = live ? row[64 * m + lane] : make_float2(0.f, 0.f);
+        }
+    }
+    static DEV void store(float2 *__restrict__ row, const float2 (&r)[16], int lane) {
+        if (WIDE) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                reinterpret_cast<float4 *>(row)[64 * m + lane] = make_float4(r[2 * m].x, r[2 * m].y, r[2 * m + 1].x, r[2 * m + 1].y);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) row[64 * m + lane] = r[m];
+        }
+    }
+    // slots -> v[m] = x[64 m + residue_of(lane)], and back (the exchange is its own inverse)
+    static DEV void to_residues(cpx (&v)[16]) {
+        if (!WIDE) return;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            exchange_halves(v[2 * m].x, v[2 * m + 1].x);
+            exchange_halves(v[2 * m].y, v[2 * m + 1].y);
+        }
+    }
+};
+
+// TGT: a target tensor is given (a template flag, not a test of the pointer inside the loop: loads inside a conditional
+// block make the compiler wait for every load in flight at the block's end, the prefetched row included)
+template <bool WIDE, bool TGT>
 __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_stats(const float2 *__restrict__ pred, const float2 *__restrict__ target,
                                                               int64_t B, const uint8_t *__restrict__ band,
                                                               float *__restrict__ stats) {
     __shared__ float2 lds[ROWS_PER_BLOCK][BUF];
     __shared__ float2 s_t1[1024], s_t2[64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    make_tw(s_t1, s_t2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = residue_of<WIDE>(lane);
+    make_tw<WIDE>(s_t1, s_t2);
     const Twiddles tw{s_t1, s_t2};
     unsigned bits[3];
     band_bits(bits, band, lane);
     // the next row's samples are loaded while the current row is transformed
     const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
     float2 nx[16], nt[16];
-    auto fetch = [&](int64_t b) {
-#pragma unroll
-        for (int m = 0; m < 16; ++m) {
-            nx[m] = b < B ? pred[b * 1024 + 64 * m + lane] : make_float2(0.f, 0.f);
-            nt[m] = (target && b < B) ? target[b * 1024 + 64 * m + lane] : make_float2(0.f, 0.f);
-        }
+    auto fetch = [&](int64_t b) {          // (index clamped, no branch around the loads; rows past the end are not used)
+        const int64_t bc = b < B ? b : B - 1;
+        RowIO<WIDE>::load(nx, pred + bc * 1024, lane, true);
+        if (TGT) RowIO<WIDE>::load(nt, target + bc * 1024, lane, true);
     };
     fetch((int64_t)blockIdx.x * ROWS_PER_BLOCK + wave);
+    DRAIN_VMEM();
     for (int64_t b = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; b < B; b += stride) {
         cpx v[16];
         float s_abs = 0.f, s_err = 0.f, s_ref = 0.f;
@@ -389,7 +455,7 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_stats(const float2 *__r
         for (int m = 0; m < 16; ++m) {
             const float2 x = nx[m];
             v[m] = {x.x, x.y};
-            if (target) {
+            if (TGT) {
                 const float2 t = nt[m];
                 const float dx = x.x - t.x, dy = x.y - t.y;
                 s_abs += fabsf(dx) + fabsf(dy);
@@ -399,7 +465,8 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_stats(const float2 *__r
         }
         fetch(b + stride);
 #ifndef ABL_NO_FFT      // experiment (timing only): the row transform left out
-        forward(v, tw, lds[wave], lane);
+        RowIO<WIDE>::to_residues(v);
+        forward(v, tw, lds[wave], lane, col);
 #endif
         float pm = 0.f, pl = 0.f, pu = 0.f;
 #pragma unroll
@@ -422,34 +489,58 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_stats(const float2 *__r
     }
 }
 
-__global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_bwd(const float2 *__restrict__ pred, const float2 *__restrict__ target,
+template <bool WIDE, bool TGT>
+__global__ __launch_bounds__(ROWS_PER_BLOCK * 64, 2) void k_bwd(const float2 *__restrict__ pred, const float2 *__restrict__ target,
                                                             int64_t B, const uint8_t *__restrict__ band,
                                                             const float *__restrict__ gstats, float2 *__restrict__ dpred) {
     __shared__ float2 lds[ROWS_PER_BLOCK][BUF];
     __shared__ float2 s_t1[1024], s_t2[64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    make_tw(s_t1, s_t2);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, col = residue_of<WIDE>(lane);
+    make_tw<WIDE>(s_t1, s_t2);
     const Twiddles tw{s_t1, s_t2};
     unsigned bits[3];
     band_bits(bits, band, lane);
-    for (int64_t b = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave; b < B; b += (int64_t)gridDim.x * ROWS_PER_BLOCK) {
-        const float2 *p = pred + b * 1024;
+    // Two resident waves per SIMD (register budget 256): the row's target and the NEXT row's samples and gradient
+    // coefficients are requested before the transforms, so their latency lies under the arithmetic of this row (the
+    // wait at the top of an iteration then covers only what was issued a whole row ago, the stores included).
+    const int64_t stride = (int64_t)gridDim.x * ROWS_PER_BLOCK;
+    const int64_t b0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK + wave;
+    float2 nx[16];
+    float ng[6];
+    auto fetch_g = [&](int64_t b) {
         const float *gs = gstats + b * 8;
-        const float g_abs = gs[0], g_err = gs[1], g_m = gs[3], g_l = gs[4], g_u = gs[5];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) ng[k] = gs[k];
+    };
+    {
+        const int64_t bc = b0 < B ? b0 : B - 1;            // (the launcher never passes an empty batch)
+        RowIO<WIDE>::load(nx, pred + bc * 1024, lane, true);
+        fetch_g(bc);
+    }
+    DRAIN_VMEM();
+    for (int64_t b = b0; b < B; b += stride) {
+        const float g_abs = ng[0], g_err = ng[1], g_m = ng[3], g_l = ng[4], g_u = ng[5];
         const bool need_fft = (g_m != 0.f) || (g_l != 0.f) || (g_u != 0.f);   // wave-uniform
-        cpx x[16], v[16];
+        float2 x[16], tg[16];
+        cpx v[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
-            const float2 t = p[64 * m + lane];
-            x[m] = {t.x, t.y};
-            v[m] = x[m];
+            x[m] = nx[m];
+            v[m] = {x[m].x, x[m].y};
+        }
+        if (TGT) RowIO<WIDE>::load(tg, target + b * 1024, lane, true);
+        {
+            const int64_t bn = b + stride < B ? b + stride : b;                     // (clamped: no branch around the loads)
+            RowIO<WIDE>::load(nx, pred + bn * 1024, lane, true);
+            fetch_g(bn);
         }
 #ifdef ABL_NO_FFT
         if (false) {
 #else
         if (need_fft) {
 #endif
-            forward(v, tw, lds[wave], lane);
+            RowIO<WIDE>::to_residues(v);
+            forward(v, tw, lds[wave], lane, col);
             // Y = conj(w X), then the transposed transform: IDFT_unnormalised(w X) = conj(F conj(w X))
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
@@ -457,9 +548,11 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_bwd(const float2 *__res
                                 (((bits[2] >> i) & 1u) ? g_u : 0.f);
                 v[i] = {w * v[i].x, -w * v[i].y};
             }
-            transposed(v, tw, lds[wave], lane);
+            transposed(v, tw, lds[wave], lane, col);
+            RowIO<WIDE>::to_residues(v);          // back to the slots of the loads
         }
         const float c2 = 2.0f / 1024.0f;
+        float2 g[16];
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             float gx = 0.f, gy = 0.f;
@@ -467,20 +560,28 @@ __global__ __launch_bounds__(ROWS_PER_BLOCK * 64) void k_bwd(const float2 *__res
                 gx = c2 * v[m].x;
                 gy = -c2 * v[m].y;
             }
-            if (target) {
-                const float2 t = target[b * 1024 + 64 * m + lane];
-                const float dx = x[m].x - t.x, dy = x[m].y - t.y;
+            if (TGT) {
+                const float dx = x[m].x - tg[m].x, dy = x[m].y - tg[m].y;
                 gx += g_abs * (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f)) + 2.f * g_err * dx;
                 gy += g_abs * (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f)) + 2.f * g_err * dy;
             }
-            dpred[b * 1024 + 64 * m + lane] = make_float2(gx, gy);
+            g[m] = make_float2(gx, gy);
         }
+        RowIO<WIDE>::store(dpred + b * 1024, g, lane);
     }
 }
 
-int grid_for_rows(int64_t B) {
+#ifndef SPECTRAL_WIDE
+#define SPECTRAL_WIDE 1            // experiment switch: 0 = 8-byte loads for every tensor
+#endif
+bool wide_ok(const void *a, const void *b, const void *c) {
+    const uintptr_t bits = reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c);
+    return SPECTRAL_WIDE && (bits & 15) == 0;
+}
+// resident blocks per CU: three by LDS (43 KB per block) for k_stats, two by registers for k_bwd
+int grid_for_rows(int64_t B, int per_cu = 3) {
     int64_t blocks = (B + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
-    if (blocks > 256 * 3) blocks = 256 * 3;      // 43 KB of LDS per block: three resident blocks per CU
+    if (blocks > 256 * per_cu) blocks = 256 * per_cu;
     return (int)(blocks < 1 ? 1 : blocks);
 }
 
@@ -829,9 +930,17 @@ extern "C" int dpd_spectral_stats(const float *pred, const float *target, int64_
         return DPD_OK;
     }
     if (band && L == 1024) {
-        hipLaunchKernelGGL(w1024::k_stats, dim3(w1024::grid_for_rows(B)), dim3(w1024::ROWS_PER_BLOCK * 64), 0,
-                           as_stream(stream), reinterpret_cast<const float2 *>(pred),
-                           reinterpret_cast<const float2 *>(target), B, band, stats);
+        // rows of 8 KiB: 16-byte loads whenever the tensors start on a 16-byte boundary
+        const bool wide = w1024::wide_ok(pred, target, nullptr);
+#define LAUNCH_STATS(W, T)                                                                                              \
+    hipLaunchKernelGGL((w1024::k_stats<W, T>), dim3(w1024::grid_for_rows(B)), dim3(w1024::ROWS_PER_BLOCK * 64), 0,          \
+                       as_stream(stream), reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), \
+                       B, band, stats)
+        if (wide && target) LAUNCH_STATS(true, true);
+        else if (wide) LAUNCH_STATS(true, false);
+        else if (target) LAUNCH_STATS(false, true);
+        else LAUNCH_STATS(false, false);
+#undef LAUNCH_STATS
         DPD_LAUNCH_CHECK();
         return DPD_OK;
     }
@@ -858,9 +967,16 @@ extern "C" int dpd_spectral_backward(const float *pred, const float *target, int
                 "spectral_backward: row length %lld is not a power of two in 2..4096", (long long)L);
     if (B <= 0) return DPD_OK;
     if (band && L == 1024) {
-        hipLaunchKernelGGL(w1024::k_bwd, dim3(w1024::grid_for_rows(B)), dim3(w1024::ROWS_PER_BLOCK * 64), 0,
-                           as_stream(stream), reinterpret_cast<const float2 *>(pred),
-                           reinterpret_cast<const float2 *>(target), B, band, gstats, reinterpret_cast<float2 *>(dpred));
+        const bool wide = w1024::wide_ok(pred, target, dpred);
+#define LAUNCH_BWD(W, T)                                                                                                 \
+    hipLaunchKernelGGL((w1024::k_bwd<W, T>), dim3(w1024::grid_for_rows(B, 2)), dim3(w1024::ROWS_PER_BLOCK * 64), 0,          \
+                       as_stream(stream), reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), \
+                       B, band, gstats, reinterpret_cast<float2 *>(dpred))
+        if (wide && target) LAUNCH_BWD(true, true);
+        else if (wide) LAUNCH_BWD(true, false);
+        else if (target) LAUNCH_BWD(false, true);
+        else LAUNCH_BWD(false, false);
+#undef LAUNCH_BWD
         DPD_LAUNCH_CHECK();
         return DPD_OK;
     }

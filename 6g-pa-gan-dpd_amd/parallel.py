@@ -24,7 +24,10 @@ def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
     one-GPU rehearsal of the multi-rank path) a device tensor is reduced through a host copy: gloo's own handling of
     device tensors is not dependable on ROCm builds (observed: two ranks on one GPU stall inside all_reduce after a
     few dozen calls), and the payloads here are a few kilobytes."""
-    if t.is_cuda and dist.get_backend(group) == "gloo" and os.environ.get("DPD_GLOO_DEVICE_TENSORS") != "1":
+    mode = os.environ.get("DPD_GLOO_DEVICE_TENSORS", "0")     # experiment switch, see below
+    if t.is_cuda and mode == "2":
+        torch.cuda.synchronize()
+    if t.is_cuda and dist.get_backend(group) == "gloo" and mode == "0":
         h = t.detach().cpu()
         dist.all_reduce(h, op=op, group=group)
         t.copy_(h)

@@ -56,11 +56,6 @@ def test_bench_two_ranks_fixed_global_problem():
     assert np.isfinite(res["value"]) and res["value"] > 0
 
 
-def test_bench_stage1_two_ranks():
-    res = _bench("--rows", "1024", "--workload", "stage1_qat")
-    assert res["n_gpus"] == 2 and np.isfinite(res["loss"]) and res["value"] > 0
-
-
 def _write_csv(path, rows):
     with open(path, "w", newline="") as f:
         w = csv.writer(f)

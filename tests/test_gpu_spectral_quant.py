@@ -94,6 +94,38 @@ def test_spectral_vs_oracle_lengths(n, rows):
     close(p.grad, rg, rtol=1e-5, atol=GTOL * float(rg.abs().max()))
 
 
+def test_spectral_1024_rows_on_an_8_byte_boundary():
+    """Rows of 1,024 samples take 16-byte loads when the tensors start on a 16-byte boundary and 8-byte loads
+    otherwise (a view that starts at an odd sample): both forms against the oracle, and against each other."""
+    from oracle import spectral as osp
+    from dpd_amd import _lib as L
+    from dpd_amd.utils.spectral_loss import band_masks
+    gen = torch.Generator().manual_seed(7)
+    rows, n = 6, 1024
+    tgt = torch.randn(rows, n, 2, generator=gen) * 0.3
+    pred = tgt + 0.05 * torch.randn(rows, n, 2, generator=gen)
+    gst = torch.rand(rows, 8, generator=gen) * 1e-2
+    band = band_masks(n, 200e6, 100e6, 100e6, DEV)
+    res = []
+    for shift in (0, 1):           # 1: every tensor one sample (8 bytes) off a 16-byte boundary
+        def dev(t):
+            buf = torch.zeros(t.numel() // 2 + 2, 2, device=DEV)
+            view = buf[shift:shift + t.numel() // 2]
+            view.copy_(t.reshape(-1, 2))
+            assert view.data_ptr() % 16 == 8 * shift
+            return view
+        p, t, dp = dev(pred), dev(tgt), dev(torch.zeros_like(pred))
+        stats = torch.empty(rows, 8, device=DEV)
+        L.call("dpd_spectral_stats", L.fptr(p), L.fptr(t), rows, n, L.fptr(band, torch.uint8), L.fptr(stats), L.stream())
+        L.call("dpd_spectral_backward", L.fptr(p), L.fptr(t), rows, n, L.fptr(band, torch.uint8), L.fptr(gst.to(DEV)), L.fptr(dp), L.stream())
+        res.append((stats.cpu(), dp.cpu().reshape(rows, n, 2)))
+    ref_stats = osp.row_stats(pred, tgt) if hasattr(osp, "row_stats") else None
+    close(res[1][0], res[0][0], rtol=1e-6, atol=1e-7)
+    close(res[1][1], res[0][1], rtol=1e-5, atol=1e-6 * float(res[0][1].abs().max()))
+    if ref_stats is not None:
+        close(res[0][0][:, :6], ref_stats[:, :6], rtol=2e-5, atol=1e-6)
+
+
 def test_spectral_other_lengths():
     """Row lengths that are not a power of two: metrics through the direct DFT (any length up to 8192, as
     torch.fft.fft in the reference takes any length) against the oracle; gradients and longer rows raise."""
@@ -114,6 +146,11 @@ def test_spectral_other_lengths():
     with pytest.raises(NotImplementedError):
         compute_acpr(torch.randn(1, 8200, 2, device=DEV))
     compute_evm(x, x * 0.9)          # no transform needed: any length
+    # the longest row of the direct-DFT path (its LDS request is above the 64 KiB a launch gets by default)
+    x = ofdm_rows(1, 8191 + 5, seed=3)[:, 5:, :].contiguous()
+    lo, up = compute_acpr(x.to(DEV))
+    rlo, rup = osp.acpr(x)
+    assert float((lo.cpu() - rlo).abs().max()) < 0.01 and float((up.cpu() - rup).abs().max()) < 0.01
 
 
 def test_fixed_point_primitives_bit_exact():
