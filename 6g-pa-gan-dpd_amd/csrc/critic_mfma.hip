@@ -1120,7 +1120,8 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__r
                                                                 float *__restrict__ score, float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) float lds[IMG_WORDS];
     build_image(lds, wb);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     const int64_t ntiles = (N + 15) >> 4;
     float acc = 0.f;
     // the tile's input is loaded one tile ahead (one value per lane): no HBM latency in front of the MFMAs
@@ -1181,7 +1182,8 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
     // that variant is gone)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // WGRAD: LDS_WORDS (> 64 KiB), else IMG_WORDS
     build_image(lds, wb);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + (WGRAD ? wave * WAVE_WORDS : 0));
     Addr ad;
     Accum ac;
@@ -1479,7 +1481,8 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
                                                           float *__restrict__ tile_sq, unsigned *__restrict__ queue) {
     __shared__ __attribute__((aligned(16))) float lds[IMG_WORDS];
     build_image(lds, wb);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     const f32x4 w4 = quad(lds, Q_W4, lane);
     const int64_t ntiles = (N + 15) >> 4;
     const unsigned tpr = ROW1 ? 1u : (unsigned)(L >> 4);      // tiles per row
@@ -1593,7 +1596,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
                                                           float *__restrict__ slab, unsigned *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // LDS_WORDS
     build_image(lds, wb);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + wave * WAVE_WORDS);
     Addr ad;
     Accum ac;
@@ -1816,7 +1820,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
                                                               unsigned *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // LDS_WORDS
     build_image(lds, wb);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + wave * WAVE_WORDS);
     Addr ad;
     Accum ac;

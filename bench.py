@@ -49,6 +49,9 @@ PA_BWD_FLOP = 400
 # the first-layer weight gradient on v_mfma_f32_4x4x1_16b_f32 (16 x 8); the hidden-layer products (60) and the weight
 # gradients of the two inner layers (30) as three-way-split bf16 operands on v_mfma_f32_16x16x32_bf16 (16 cycles)
 CRITIC_BWD_BF16_MFMA = 90
+# k_q88_mfma, per chunk of 64 samples and wave, counted in the loop body of the compiled kernel (scratch/isa_hist.py)
+Q88_VALU_PER_CHUNK = 634
+Q88_MFMA_PER_CHUNK = 40
 CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + CRITIC_BWD_BF16_MFMA * 16
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
@@ -311,24 +314,34 @@ def q88_engine(ctx):
 def q88_roof(ctx, k, eng):
     n = ctx.rows * (ctx.seq - 5)
     mac = GEN_FWD_MAC * n
-    # integer-VALU ceiling: v_dot2c_i32_i16 issues at 16 lanes per SIMD-cycle (half the fp32 FMA rate; scratch/ubench/dot2_rate.hip
-    # measures 36.4 T lane-instructions/s): 256 CU x 4 SIMD x 16 lanes x 2 MAC x 2.4 GHz = 78.6 TMAC/s
-    roof = {"bound": "valu-int", "achieved": mac / k / 1e12, "peak": 78.6, "unit": "TMAC/s", "frac": mac / k / 1e12 / 78.6,
-            "traffic": None, "hbm_gbs": 8.0 * n / k / 1e9, "kernel_ms": k * 1e3, "mac_per_sample": GEN_FWD_MAC}
+    hbm = 8.0 * n / k / 1e9                  # 4 B in + 4 B out per sample
     if getattr(eng, "mode", 0) == 2:
-        # matrix-core form: every int16 MAC is four int8 MACs (two digits per operand); the kernel executes 10,240 int8 MACs per
-        # sample (6 + 3 MFMAs of 16x16x64 per 16 samples and 4 per 64 samples, K partly padding) against 6,016 useful ones.  Dense
-        # int8 MFMA peak: twice the bf16 rate = 2.5e15 MAC/s
-        roof.update(kernel="k_q88_mfma (v_mfma_i32_16x16x64_i8, int16 = two 8-bit digits, three int32 accumulators per product)",
-                    frac_definition="int16 MACs per second against the integer-VALU ceiling of v_dot2c_i32_i16 (the roofline of the "
-                                    "VALU form of this path); above 1 means the matrix cores carry the MACs faster than the VALU could",
-                    mfma_i8_frac=10240.0 * n / k / 2.5e15, mfma_i8_useful_frac=4.0 * mac / k / 2.5e15,
-                    traffic=pmc_bytes("k_q88_mfma") if default_shape(ctx) else None,
-                    note="bound by the requantisation around the products (about 10 integer VALU instructions per neuron and sample), "
-                         "not by the matrix pipe or HBM")
-    else:
-        roof.update(kernel="k_q88 (v_dot2c_i32_i16)", acc64=eng.acc64, traffic=pmc_bytes("k_q88<false>") if default_shape(ctx) else None)
-    return roof
+        # Matrix-core form.  What bounds it is the issue port of the SIMDs: per chunk of 64 samples a wave issues
+        # Q88_VALU_PER_CHUNK vector-ALU instructions (requantisation, LeakyReLU, digit split, feature planes; counted in the
+        # kernel's ISA, scratch/isa_hist.py) and 40 MFMAs.  A wave64 VALU instruction holds the port of its SIMD for 4 cycles,
+        # an int8 MFMA for 4 of its 16: the floor is (634 x 4 + 40 x 4) cycles per chunk and SIMD.  frac = that floor over the
+        # measured kernel time; the matrix pipe and HBM are reported beside it and are far from their peaks.
+        chunks_per_simd = n / 64.0 / N_SIMD
+        issue_s = chunks_per_simd * (Q88_VALU_PER_CHUNK * 4 + Q88_MFMA_PER_CHUNK * 4) / CLOCK_HZ
+        ginst = (Q88_VALU_PER_CHUNK + Q88_MFMA_PER_CHUNK) * (n / 64.0) / k / 1e9
+        peak = N_SIMD * CLOCK_HZ / 4 / 1e9
+        return {"bound": "valu-issue", "achieved": ginst, "peak": peak, "unit": "G wave-instructions/s", "frac": issue_s / k,
+                "frac_definition": "vector issue time of one launch (634 VALU + 40 MFMA wave-instructions per 64 samples, 4 cycles each "
+                                   "on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
+                "kernel": "k_q88_mfma (v_mfma_i32_16x16x64_i8, int16 = two 8-bit digits, three int32 accumulators per product)",
+                "issue_floor_ms": issue_s * 1e3, "kernel_ms": k * 1e3, "valu_per_64_samples": Q88_VALU_PER_CHUNK,
+                "mfma_per_64_samples": Q88_MFMA_PER_CHUNK, "mac_per_sample": GEN_FWD_MAC, "tmac_per_s": mac / k / 1e12,
+                # the other ceilings of this kernel, for scale: executed and useful int8 MACs against the dense int8 MFMA peak
+                # (2.5e15 MAC/s; 10,240 executed per sample, 6,016 useful), and bytes against HBM
+                "mfma_i8_frac": 10240.0 * n / k / 2.5e15, "mfma_i8_useful_frac": 4.0 * mac / k / 2.5e15,
+                "hbm_gbs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
+                "traffic": pmc_bytes("k_q88_mfma") if default_shape(ctx) else None}
+    # integer-VALU form: v_dot2c_i32_i16 issues at 16 lanes per SIMD-cycle (half the fp32 FMA rate; scratch/ubench/dot2_rate.hip
+    # measures 36.4 T lane-instructions/s): 256 CU x 4 SIMD x 16 lanes x 2 MAC x 2.4 GHz = 78.6 TMAC/s
+    return {"bound": "valu-int", "achieved": mac / k / 1e12, "peak": 78.6, "unit": "TMAC/s", "frac": mac / k / 1e12 / 78.6,
+            "kernel": "k_q88 (v_dot2c_i32_i16)", "acc64": eng.acc64, "hbm_gbs": hbm, "hbm_frac": hbm / HBM_PEAK_GBS,
+            "kernel_ms": k * 1e3, "mac_per_sample": GEN_FWD_MAC,
+            "traffic": pmc_bytes("k_q88<false>") if default_shape(ctx) else None}
 
 
 def run_q88(ctx, args, steps, warmup):

@@ -1,4 +1,6 @@
 """Helpers shared by the GPU parity tests."""
+import os
+
 import numpy as np
 import torch
 
@@ -18,6 +20,14 @@ def sd(g, prefix):
 def close(a, b, rtol=1e-5, atol=1e-6):
     a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
     b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    if os.environ.get("DPD_CLOSE_REPORT"):
+        # how much of the allowance a comparison uses: max |a - b| / (atol + rtol |b|), with the caller's line
+        import inspect
+        f = inspect.stack()[1]
+        d = np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64))
+        use = float(np.max(d / np.maximum(atol + rtol * np.abs(b), 1e-300))) if d.size else 0.0
+        print(f"close: {os.path.basename(f.filename)}:{f.lineno} used {use:.4f} of rtol={rtol:g} atol={atol:g} "
+              f"max|d|={float(d.max()) if d.size else 0:.3e} max|b|={float(np.abs(b).max()) if d.size else 0:.3e}")
     np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
 
 
@@ -33,7 +43,6 @@ def close_q(a, b, frac=None):
     lsb = np.abs(b).max() / 32767
     assert np.abs(a - b).max() <= lsb + 1e-5 * np.abs(b).max(), (np.abs(a - b).max(), lsb)  # one step + fp32 tolerance on the scale
     same = np.abs(a - b) <= 2e-6 * np.abs(b) + 1e-9
-    import os
     if os.environ.get("DPD_CLOSEQ_REPORT"):
         print(f"close_q: n={a.size} equal fraction {same.mean():.6f} max|d|/lsb {np.abs(a - b).max() / lsb:.4f}")
     allowed = max(5, int(np.ceil(0.02 * a.size))) if frac is None else int(np.floor((1 - frac) * a.size))

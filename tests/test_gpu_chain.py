@@ -46,8 +46,8 @@ def test_csv_slice_through_the_chain():
     dpd, y = dpd_pa_chain(gen, pa, iq)
     close_q(dpd, g["dpd"])
     scale = float(np.abs(g["y"]).max())
-    # the PA gain (31.6) multiplies the generator's one-step quantisation differences
-    close(y, g["y"], rtol=1e-5, atol=2e-4 * scale)
+    # measured on MI355X: 1.4e-7 of the peak (no generator output lands on the other side of a rounding boundary here)
+    close(y, g["y"], rtol=1e-5, atol=2e-6 * scale)
     # the module-by-module route gives the same
     with torch.no_grad():
         y_mod = pa(gen(iq), add_noise=False)
@@ -97,9 +97,11 @@ def test_chain_backward_vs_oracle_autograd(qat, shape):
     got = torch.cat([p.grad.reshape(-1) for p in (gen.fc1.weight, gen.fc1.bias, gen.fc2.weight, gen.fc2.bias,
                                                   gen.fc3.weight, gen.fc3.bias)]).cpu()
     scale = float(y_ref.abs().max())
-    close(y, y_ref.numpy(), rtol=1e-4, atol=(3e-6 if not qat else 3e-4) * scale)
-    # QAT: an activation that lands on the other side of a rounding boundary moves a gradient term by one step
-    close(got, g_ref.numpy(), rtol=3e-4, atol=(1e-4 if not qat else 1e-3) * float(g_ref.abs().max()))
+    # measured on MI355X over these shapes, as a fraction of the peak: float 6.5e-7, QAT 3.1e-5 (a generator output on
+    # the other side of a rounding boundary is one 16-bit step, which the PA gain multiplies); gradients 2.3e-7 and
+    # 2.8e-6 of the largest entry.  The allowances are about three times that.
+    close(y, y_ref.numpy(), rtol=1e-5, atol=(2e-6 if not qat else 1e-4) * scale)
+    close(got, g_ref.numpy(), rtol=1e-5, atol=(1e-6 if not qat else 1e-5) * float(g_ref.abs().max()))
 
 
 @pytest.mark.parametrize("qat", [False, True])
@@ -129,8 +131,9 @@ def test_chain_mse_step_vs_oracle(qat, shape):
     L.call("dpd_gen_pa_mse_step", L.fptr(x), B, S, L.fptr(tg), L.fptr(wq), 0.2, int(qat), L.fptr(absmax), L.fptr(cre_d),
            L.fptr(cim_d), 4, 5, L.fptr(res), L.fptr(res[L.GEN_NPARAM:]), wsp, wsn, st)
     res = res.cpu()
-    close(res[L.GEN_NPARAM], loss_ref.numpy(), rtol=1e-5 if not qat else 1e-3)
-    close(res[:L.GEN_NPARAM], g_ref.numpy(), rtol=3e-4, atol=(1e-4 if not qat else 1e-3) * float(g_ref.abs().max()))
+    # measured on MI355X: loss 1.1e-7 relative, gradients 1.9e-7 of the largest entry (float and QAT alike)
+    close(res[L.GEN_NPARAM], loss_ref.numpy(), rtol=1e-6)
+    close(res[:L.GEN_NPARAM], g_ref.numpy(), rtol=1e-5, atol=(1e-6 if not qat else 3e-6) * float(g_ref.abs().max()))
 
 
 def test_chain_backward_other_pa_shapes_and_step():
@@ -154,7 +157,7 @@ def test_chain_backward_other_pa_shapes_and_step():
         (y * gy.to(DEV)).sum().backward()
         got = torch.cat([p.grad.reshape(-1) for p in (gen.fc1.weight, gen.fc1.bias, gen.fc2.weight, gen.fc2.bias,
                                                       gen.fc3.weight, gen.fc3.bias)]).cpu()
-        close(got, g_ref.numpy(), rtol=3e-4, atol=1e-4 * float(g_ref.abs().max()))
+        close(got, g_ref.numpy(), rtol=1e-5, atol=1e-6 * float(g_ref.abs().max()))     # measured: 2.8e-7 of the largest entry
     # one optimiser step
     gen, params = _generator(True, seed=14)
     gen.train()
@@ -171,7 +174,7 @@ def test_chain_backward_other_pa_shapes_and_step():
     opt.step()
     step = ChainStep(gen, pa)
     loss = step(iq.to(DEV), target.to(DEV))
-    close(loss, loss_ref.numpy().reshape(1), rtol=1e-3)
+    close(loss, loss_ref.numpy().reshape(1), rtol=1e-5)
     for p, r in zip((gen.fc1.weight, gen.fc1.bias, gen.fc2.weight, gen.fc2.bias, gen.fc3.weight, gen.fc3.bias), ref_p):
         # Adam's first step moves every entry by lr * sign(g): entries whose tiny gradient differs in sign aside
         diff = (p.detach().cpu() - r.detach()).abs()
@@ -206,8 +209,8 @@ def test_gen_pa_forward_qat_entry_point(shape):
     d_c, y_c = dpd_pa_chain(gen, pa, x)
     close_q(dpd, d_c.cpu().numpy())
     scale = float(y_c.abs().max())
-    close(y, y_c.detach().cpu().numpy(), rtol=1e-5, atol=2e-4 * scale)
+    close(y, y_c.detach().cpu().numpy(), rtol=1e-5, atol=2e-6 * scale)       # measured: 3.4e-7 of the peak
     # the four scales against the oracle's: the abs-max of each quantiser input, to one unit in the last place
     d_ref = og.gen_forward(x.cpu(), params, qat=True)
     y_ref = opa.volterra_forward(d_ref, cre.cpu(), cim.cpu())
-    close(y, y_ref.numpy(), rtol=1e-4, atol=3e-4 * scale)
+    close(y, y_ref.numpy(), rtol=1e-5, atol=1e-4 * scale)                       # measured: 3.0e-5 of the peak

@@ -33,13 +33,13 @@ def test_pa_twin_golden():
         close(pa.pa_model.coeffs_imag, g[f"coef_im_{st}"], rtol=1e-6, atol=1e-9)
         close(y, g[f"y_{st}"], rtol=1e-5, atol=2e-5)
         (y ** 2).sum().backward()
-        close(xg.grad, g[f"dx_{st}"], rtol=1e-4, atol=2e-2)
+        close(xg.grad, g[f"dx_{st}"], rtol=1e-5, atol=2e-3)      # entries up to 1.7e3; measured error 6.1e-4
     pa.set_temperature_state("normal")
     xz = T(g["xz"]).requires_grad_(True)
     y0 = pa(xz, add_noise=False)
     close(y0, g["y_zero"], rtol=1e-5, atol=2e-5)
     y0.backward(T(g["gy_zero"]))
-    close(xz.grad, g["dx_zero"], rtol=1e-4, atol=1e-3)
+    close(xz.grad, g["dx_zero"], rtol=1e-5, atol=5e-5)       # entries up to 1e2; measured error 1.5e-5
     xc = torch.complex(x[..., 0], x[..., 1])
     close(pa.pa_model(xc), g["y_complex_in"], rtol=1e-5, atol=2e-5)
     with pytest.raises(ValueError):
@@ -96,9 +96,9 @@ def test_critic_forward_backward_golden(critic_impl):
     out3 = d(xg, c3)
     close(out3, g["train_out3"], rtol=1e-5, atol=1e-5 * np.abs(g["train_out3"]).max())
     out3.backward(T(g["train_gs3"]))
-    close(xg.grad, g["train_dx3"], rtol=1e-4, atol=1e-6)
+    close(xg.grad, g["train_dx3"], rtol=2e-5, atol=1e-6)
     for n, p in d.named_parameters():
-        close(p.grad, g["grad3__" + n.replace(".", "__")], rtol=2e-4, atol=2e-4)
+        close(p.grad, g["grad3__" + n.replace(".", "__")], rtol=2e-5, atol=1e-5)
     from dpd_amd.models import Discriminator
     dn = Discriminator(use_spectral_norm=False)
     dn.load_state_dict(sd(g, "nosn__"))
@@ -131,17 +131,17 @@ def test_gradient_penalty_and_losses_golden(critic_impl):
     total, info = wl.discriminator_loss(d, real, fake, cond, dev, alpha=T(g["dl_alpha"]))
     close(total, g["dl_total"], rtol=1e-5)
     for k in ("d_loss", "gp", "w_distance", "real_score", "fake_score"):
-        close(info[k], g["dl_info__" + k], rtol=1e-4, atol=1e-6)
+        close(info[k], g["dl_info__" + k], rtol=1e-5, atol=1e-6)
     total.backward()
     for n, p in d.named_parameters():
-        close(p.grad, g["dlgrad__" + n.replace(".", "__")], rtol=3e-4, atol=3e-5)
+        close(p.grad, g["dlgrad__" + n.replace(".", "__")], rtol=3e-5, atol=3e-6)
     for k, v in d.state_dict().items():
         close(v, g["sd1__" + k.replace(".", "__")], rtol=1e-5, atol=1e-7)
     fg = fake.clone().requires_grad_(True)
     gl, ginfo = wl.generator_loss(d, fg, cond)
     close(gl, g["gl"], rtol=1e-5)
     gl.backward()
-    close(fg.grad, g["gl_dfake"], rtol=1e-4, atol=1e-9)
+    close(fg.grad, g["gl_dfake"], rtol=2e-5, atol=1e-9)
     # default alpha path draws torch.rand(B, 1) on the device: only finiteness is defined
     assert torch.isfinite(compute_gradient_penalty(d, real, fake, cond, dev))
 
@@ -177,7 +177,7 @@ def test_gradient_penalty_vs_oracle_ragged(shape, critic_impl):
     close(gp, ref.detach(), rtol=2e-5)
     gp.backward()
     for lin, rg in zip(d._layers(), ref_g):
-        close(lin.weight_orig.grad, rg, rtol=3e-4, atol=3e-6)
+        close(lin.weight_orig.grad, rg, rtol=5e-5, atol=5e-7)
 
 
 @pytest.mark.parametrize("shape", [(1, 512), (9, 1024), (70, 512), (33, 2048), (40, 256), (21, 768)])

@@ -41,7 +41,7 @@ def test_spectral_golden():
         assert np.abs(lo.cpu().numpy() - g[f"L{n}_acpr_lo_db"]).max() < 1e-2   # bar: 0.1 dB
         assert np.abs(up.cpu().numpy() - g[f"L{n}_acpr_up_db"]).max() < 1e-2
         lo, up = compute_acpr(p, return_db=False)
-        close(lo, g[f"L{n}_acpr_lo_lin"], rtol=2e-4); close(up, g[f"L{n}_acpr_up_lin"], rtol=2e-4)
+        close(lo, g[f"L{n}_acpr_lo_lin"], rtol=1e-5); close(up, g[f"L{n}_acpr_up_lin"], rtol=1e-5)
         m = sl.compute_metrics(p, tgt)
         for k, v in m.items():
             ref = float(g[f"L{n}_metric__{k}"])
@@ -64,7 +64,7 @@ def test_spectral_golden():
     close(p256.grad, g["evmloss_d"], rtol=1e-5, atol=GTOL * np.abs(g["evmloss_d"]).max())
     p256 = T(g["L256_pred"]).requires_grad_(True)
     al = ACPRLoss()(p256)
-    close(al, g["acprloss"], rtol=1e-4)
+    close(al, g["acprloss"], rtol=1e-5)
     al.backward()
     close(p256.grad, g["acprloss_d"], rtol=1e-5, atol=GTOL * np.abs(g["acprloss_d"]).max())
 
