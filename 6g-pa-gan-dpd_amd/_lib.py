@@ -22,6 +22,7 @@ c_p, c_i, c_l, c_f, c_sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes
 # name -> argument types (all return int unless listed in _RESTYPES)
 PROTOTYPES = {
     "dpd_tap_assembly": [c_p, c_l, c_l, c_p, c_p],
+    "dpd_tap_assembly_backward": [c_p, c_l, c_l, c_p, c_p, c_p],
     "dpd_gen_prepare_weights": [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_p, c_p, c_p],
     "dpd_gen_absmax_pass": [c_i, c_p, c_l, c_l, c_i, c_p, c_f, c_p, c_p, c_i, c_p],
     "dpd_gen_uses_mfma": [c_l, c_l, c_i, c_i],

@@ -5,6 +5,7 @@
 int gen_launch_prepare(const float *, const float *, const float *, const float *, const float *, const float *, int,
                        float *, float *, hipStream_t);
 int gen_launch_taps(const float *, int64_t, int64_t, float *, hipStream_t);
+int gen_launch_tap_adjoint(const float *, int64_t, int64_t, const float *, float *, hipStream_t);
 int gen_launch_quantize_output(float *, int64_t, const float *, hipStream_t);
 
 namespace {
@@ -51,6 +52,13 @@ extern "C" int dpd_tap_assembly(const float *iq, int64_t B, int64_t S, float *fe
     DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
     if (B <= 0) return DPD_OK;
     return gen_launch_taps(iq, B, S, feat, as_stream(stream));
+}
+
+extern "C" int dpd_tap_assembly_backward(const float *iq, int64_t B, int64_t S, const float *gfeat, float *dx, void *stream) {
+    DPD_REQUIRE((iq && gfeat && dx) || B == 0, DPD_ERR_INVALID_ARG, "tap_assembly_backward: null pointer");
+    DPD_REQUIRE(S > DPD_GEN_MEMORY, DPD_ERR_SHAPE, "Sequence length %lld must be > memory depth %d", (long long)S, DPD_GEN_MEMORY);
+    if (B <= 0) return DPD_OK;
+    return gen_launch_tap_adjoint(iq, B, S, gfeat, dx, as_stream(stream));
 }
 
 extern "C" int dpd_gen_prepare_weights(const float *w1, const float *b1, const float *w2, const float *b2,

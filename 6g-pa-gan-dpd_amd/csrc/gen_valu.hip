@@ -353,6 +353,34 @@ __global__ __launch_bounds__(256) void k_tap_assembly(const float *__restrict__ 
     }
 }
 
+// Adjoint of the tap assembly (the reference's MemoryTapAssembly is differentiable torch, models/tdnn_generator.py:158-195):
+// dx[b, s] = sum over the outputs n = s - 5 + g (g = 0..5, 0 <= n < L) that read point s as their tap g of
+//   the gradient of the IQ columns of that tap + (gf_e + 2 e gf_e2 + 4 e^3 gf_e4) x / e,   e = |x[b, s]|
+// (columns: 0, 1 current IQ; 2 + g, 8 + g, 14 + g the envelope and its powers of tap g; 20 + 2 (g - 1), + 1 the IQ of
+// tap g >= 1).  One thread per point, a gather: no atomics, bitwise reproducible.  At e = 0 the envelope terms are
+// dropped (torch's sqrt has no finite derivative there).
+__global__ __launch_bounds__(256) void k_tap_adjoint(const float2 *__restrict__ iq, int64_t B, int64_t S, int64_t L,
+                                                     const float *__restrict__ gfeat, float2 *__restrict__ dx) {
+    const int64_t n_pts = B * S;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n_pts; i += (int64_t)gridDim.x * 256) {
+        const int64_t b = i / S, s = i - b * S;
+        const float2 v = iq[i];
+        const float e = sqrtf(v.x * v.x + v.y * v.y), e2 = e * e;
+        float gi = 0.f, gq = 0.f, ge = 0.f;
+#pragma unroll
+        for (int g = 0; g < 6; ++g) {
+            const int64_t n = s - 5 + g;
+            if (n < 0 || n >= L) continue;
+            const float *f = gfeat + (b * L + n) * 30;
+            gi += g == 0 ? f[0] : f[20 + 2 * (g - 1)];
+            gq += g == 0 ? f[1] : f[21 + 2 * (g - 1)];
+            ge += f[2 + g] + 2.f * e * f[8 + g] + 4.f * e2 * e * f[14 + g];
+        }
+        const float r = e > 0.f ? ge / e : 0.f;
+        dx[i] = make_float2(gi + r * v.x, gq + r * v.y);
+    }
+}
+
 template <bool PRE, bool QAT>
 int launch_fwd(const GenProblem &p, int depth, float *out, hipStream_t st) {
     const int grid = grid_for(p.N, FWD_TPB);
@@ -431,6 +459,14 @@ int gen_launch_prepare(const float *w1, const float *b1, const float *w2, const 
 int gen_launch_taps(const float *iq, int64_t B, int64_t S, float *feat, hipStream_t st) {
     const int64_t L = S - 5, N = B * L;
     hipLaunchKernelGGL(k_tap_assembly, dim3(grid_for(N, 256)), dim3(256), 0, st, iq, N, S, L, feat);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+int gen_launch_tap_adjoint(const float *iq, int64_t B, int64_t S, const float *gfeat, float *dx, hipStream_t st) {
+    const int64_t L = S - 5;
+    hipLaunchKernelGGL(k_tap_adjoint, dim3(grid_for(B * S, 256)), dim3(256), 0, st, reinterpret_cast<const float2 *>(iq), B, S, L,
+                       gfeat, reinterpret_cast<float2 *>(dx));
     DPD_LAUNCH_CHECK();
     return DPD_OK;
 }

@@ -191,6 +191,71 @@ __global__ __launch_bounds__(TPB) void k_spectral_bwd(const float2 *__restrict__
     }
 }
 
+// The gradient for row lengths that are not a power of two: both transforms as direct sums over the tabulated
+// twiddles (the reference differentiates torch.fft.fft of any length, utils/spectral_loss.py:99-103).  The weighted
+// spectrum Y[k] = w_k X[k] is parked in LDS next to the twiddles (2 L complex words); the row itself is read from
+// global memory by every thread at the same address (a broadcast).  O(L^2) per row and workgroup.
+__global__ __launch_bounds__(TPB) void k_spectral_bwd_dft(const float2 *__restrict__ pred, const float2 *__restrict__ target,
+                                                          int64_t L, const uint8_t *__restrict__ band,
+                                                          const float *__restrict__ gstats, float2 *__restrict__ dpred) {
+    extern __shared__ float2 lds2[];
+    float2 *tw = lds2, *Y = lds2 + L;
+    const int64_t b = blockIdx.x;
+    const float2 *p = pred + b * L;
+    const float *gs = gstats + b * 8;
+    const float g_abs = gs[0], g_err = gs[1], g_m = gs[3], g_l = gs[4], g_u = gs[5];
+    const bool need_dft = band != nullptr && ((g_m != 0.f) || (g_l != 0.f) || (g_u != 0.f));   // block-uniform
+    const int n_len = (int)L;
+    if (need_dft) {
+        for (int r = threadIdx.x; r < n_len; r += TPB) {
+            float sn, cs;
+            sincospif(2.0f * (float)r / (float)n_len, &sn, &cs);
+            tw[r] = make_float2(cs, -sn);
+        }
+        __syncthreads();
+        for (int k = threadIdx.x; k < n_len; k += TPB) {
+            const float w = (band[k] ? g_m : 0.f) + (band[L + k] ? g_l : 0.f) + (band[2 * L + k] ? g_u : 0.f);
+            float xr = 0.f, xi = 0.f;
+            if (w != 0.f) {
+                int r = 0;
+                for (int n = 0; n < n_len; ++n) {
+                    const float2 v = p[n], t = tw[r];
+                    xr += v.x * t.x - v.y * t.y;
+                    xi += v.x * t.y + v.y * t.x;
+                    r += k;
+                    if (r >= n_len) r -= n_len;
+                }
+            }
+            Y[k] = make_float2(w * xr, w * xi);
+        }
+        __syncthreads();
+    }
+    const float c2 = 2.0f / (float)L;
+    for (int i = threadIdx.x; i < n_len; i += TPB) {
+        float gx = 0.f, gy = 0.f;
+        if (need_dft) {
+            float zr = 0.f, zi = 0.f;     // Z[i] = sum_k Y[k] exp(+2 pi i k i / L)
+            int r = 0;
+            for (int k = 0; k < n_len; ++k) {
+                const float2 y = Y[k], t = tw[r];
+                zr += y.x * t.x + y.y * t.y;
+                zi += y.y * t.x - y.x * t.y;
+                r += i;
+                if (r >= n_len) r -= n_len;
+            }
+            gx = c2 * zr;
+            gy = c2 * zi;
+        }
+        if (target) {
+            const float2 v = p[i], t = target[b * L + i];
+            const float dx = v.x - t.x, dy = v.y - t.y;
+            gx += g_abs * (dx > 0.f ? 1.f : (dx < 0.f ? -1.f : 0.f)) + 2.f * g_err * dx;
+            gy += g_abs * (dy > 0.f ? 1.f : (dy < 0.f ? -1.f : 0.f)) + 2.f * g_err * dy;
+        }
+        dpred[b * L + i] = make_float2(gx, gy);
+    }
+}
+
 
 // ------------------------------------------------------------------ L = 1024: one wave per row, FFT in registers
 // 1024 = 16 x 16 x 4.  Lane l holds x[64 m + l], m = 0..15 (coalesced loads).  Forward transform:
@@ -963,9 +1028,25 @@ extern "C" int dpd_spectral_backward(const float *pred, const float *target, int
     DPD_REQUIRE(((pred && gstats && dpred && (band || target)) || B <= 0), DPD_ERR_INVALID_ARG, "spectral_backward: null pointer");
     DPD_REQUIRE(L >= 1, DPD_ERR_INVALID_ARG, "spectral_backward: empty rows");
     int log2n = 0;
-    DPD_REQUIRE(!band || check_len(L, &log2n), DPD_ERR_INVALID_ARG,
-                "spectral_backward: row length %lld is not a power of two in 2..4096", (long long)L);
+    const bool pow2 = check_len(L, &log2n);
+    DPD_REQUIRE(!band || pow2 || (L >= 2 && L <= 8192), DPD_ERR_INVALID_ARG,
+                "spectral_backward: row length %lld is neither a power of two in 2..4096 nor within the direct-DFT limit of 8192", (long long)L);
     if (B <= 0) return DPD_OK;
+    if (band && !pow2) {
+        // twiddles and the weighted spectrum in dynamic LDS: up to 128 KiB, above what a launch gets without the attribute
+        static PerDeviceOnce attr_once;
+        int attr_dev;
+        if (attr_once.first_use(&attr_dev)) {
+            DPD_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_spectral_bwd_dft),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)(2 * 8192 * sizeof(float2))));
+            attr_once.mark(attr_dev);
+        }
+        hipLaunchKernelGGL(k_spectral_bwd_dft, dim3((unsigned)B), dim3(TPB), (size_t)2 * L * sizeof(float2), as_stream(stream),
+                           reinterpret_cast<const float2 *>(pred), reinterpret_cast<const float2 *>(target), L, band, gstats,
+                           reinterpret_cast<float2 *>(dpred));
+        DPD_LAUNCH_CHECK();
+        return DPD_OK;
+    }
     if (band && L == 1024) {
         const bool wide = w1024::wide_ok(pred, target, dpred);
 #define LAUNCH_BWD(W, T)                                                                                                 \

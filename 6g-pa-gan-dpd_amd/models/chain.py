@@ -9,7 +9,7 @@ import torch
 
 from .. import _lib as L
 from .pa_digital_twin import PADigitalTwin, VolterraPA
-from .tdnn_generator import TDNNGenerator, TDNNGeneratorQAT
+from .tdnn_generator import TDNNGenerator, TDNNGeneratorQAT, iq_rows_backward
 
 _SIZES = [960, 32, 512, 16, 32, 2]
 
@@ -56,9 +56,23 @@ class _ChainFn(torch.autograd.Function):
     def backward(ctx, gy, _gdpd):
         x, wq, absmax, cre, cim = ctx.saved_tensors
         B, S, K, M, slope, qat = ctx.cfg
-        if ctx.needs_input_grad[0]:
-            raise NotImplementedError("dpd_pa_chain: gradient w.r.t. the IQ rows is not provided by the HIP path")
         grads = torch.empty(L.GEN_NPARAM, dtype=torch.float32, device=x.device)
+        if ctx.needs_input_grad[0]:
+            # the IQ rows ask for a gradient: the separate kernels (generator output recomputed with the scales of the
+            # forward, PA adjoint, generator backward on pre-assembled features, adjoint of the tap assembly)
+            st = L.stream()
+            dpd = torch.empty(B, S - 5, 2, dtype=torch.float32, device=x.device)
+            if qat:
+                tmp = absmax.clone()
+                L.call("dpd_gen_absmax_pass", 3, L.fptr(x), B, S, 0, L.fptr(wq), slope, L.fptr(tmp), L.fptr(dpd), 0, st)
+                L.call("dpd_gen_quantize_output", L.fptr(dpd), dpd.numel(), L.fptr(absmax), st)
+            else:
+                L.call("dpd_gen_forward", L.fptr(x), B, S, 0, L.fptr(wq), slope, 0, L.fptr(absmax), L.fptr(dpd), 0, st)
+            gd = torch.empty_like(dpd)
+            L.call("dpd_pa_backward", L.fptr(dpd), B, S - 5, L.fptr(cre), L.fptr(cim), K, M, L.fptr(L.as_f32(gy)), L.fptr(gd), st)
+            gx = iq_rows_backward(x, B, S, wq, slope, qat, absmax, gd, grads)
+            parts = [g.view(s) for g, s in zip(torch.split(grads, _SIZES), ctx.shapes)]
+            return (gx, *parts, None, None, None, None, None, None)
         _, wsp, wsn = L.workspace(x.device, B * (S - 5))
         L.call("dpd_gen_pa_backward", L.fptr(x), B, S, L.fptr(wq), slope, int(qat), L.fptr(absmax), L.fptr(cre),
                L.fptr(cim), K, M, L.fptr(L.as_f32(gy)), L.fptr(grads), wsp, wsn, L.stream())

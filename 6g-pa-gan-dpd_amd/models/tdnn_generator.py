@@ -82,11 +82,16 @@ class _TapFn(torch.autograd.Function):
         B, S, _ = x.shape
         feat = torch.empty(B, max(S - 5, 0), 30, dtype=torch.float32, device=x.device)
         L.call("dpd_tap_assembly", L.fptr(x), B, S, L.fptr(feat), L.stream())
+        ctx.save_for_backward(x)
         return feat
 
     @staticmethod
     def backward(ctx, g):
-        raise NotImplementedError("MemoryTapAssembly: gradient w.r.t. the IQ input is not provided by the HIP path")
+        (x,) = ctx.saved_tensors
+        B, S, _ = x.shape
+        dx = torch.empty_like(x)
+        L.call("dpd_tap_assembly_backward", L.fptr(x), B, S, L.fptr(L.as_f32(g)), L.fptr(dx), L.stream())
+        return dx
 
 
 class MemoryTapAssembly(nn.Module):
@@ -152,16 +157,34 @@ class _GenFn(torch.autograd.Function):
     def backward(ctx, gout, _gabs):
         xc, wq, absmax = ctx.saved_tensors
         B, S, pre, slope, qat, impl, x_needs_grad = ctx.cfg
-        if x_needs_grad and not pre:
-            raise NotImplementedError("generator: gradient w.r.t. the IQ rows is not provided by the HIP path")
         grads = torch.empty(L.GEN_NPARAM, dtype=torch.float32, device=xc.device)
-        gfeat = torch.empty_like(xc) if (pre and x_needs_grad) else None
         _, wsp, wsn = L.workspace(xc.device)
-        L.call("dpd_gen_backward", L.fptr(xc), B, S, int(pre), L.fptr(wq), slope, int(qat), L.fptr(absmax),
-               L.fptr(L.as_f32(gout)), L.fptr(grads), L.fptr(gfeat), wsp, wsn, impl, L.stream())
+        if x_needs_grad and not pre:
+            gx = iq_rows_backward(xc, B, S, wq, slope, qat, absmax, L.as_f32(gout), grads)
+        else:
+            gx = torch.empty_like(xc) if (pre and x_needs_grad) else None
+            L.call("dpd_gen_backward", L.fptr(xc), B, S, int(pre), L.fptr(wq), slope, int(qat), L.fptr(absmax),
+                   L.fptr(L.as_f32(gout)), L.fptr(grads), L.fptr(gx), wsp, wsn, impl, L.stream())
         sizes = [960, 32, 512, 16, 32, 2]
         parts = [g.view(s) for g, s in zip(torch.split(grads, sizes), ctx.shapes)]
-        return (gfeat, *parts, None, None, None, None, None)
+        return (gx, *parts, None, None, None, None, None)
+
+
+def iq_rows_backward(x, B, S, wq, slope, qat, absmax, gout, grads):
+    """Backward of the generator when the IQ rows themselves ask for a gradient (no caller in the reference does; its
+    generator is differentiable torch, models/tdnn_generator.py:158-195, :257-287).  Three launches instead of the
+    fused kernel: features to HBM, the backward on pre-assembled features (parameter gradients into `grads`, gradient of
+    the features; the scales are those of the forward), the adjoint of the tap assembly.  Returns dx [B, S, 2]."""
+    st = L.stream()
+    feat = torch.empty(B * (S - 5), 30, dtype=torch.float32, device=x.device)
+    L.call("dpd_tap_assembly", L.fptr(x), B, S, L.fptr(feat), st)
+    gfeat = torch.empty_like(feat)
+    _, wsp, wsn = L.workspace(x.device)
+    L.call("dpd_gen_backward", L.fptr(feat), B * (S - 5), 0, 1, L.fptr(wq), slope, int(qat), L.fptr(absmax),
+           L.fptr(gout), L.fptr(grads), L.fptr(gfeat), wsp, wsn, L.IMPL_AUTO, st)
+    dx = torch.empty_like(x)
+    L.call("dpd_tap_assembly_backward", L.fptr(x), B, S, L.fptr(gfeat), L.fptr(dx), st)
+    return dx
 
 
 class _GeneratorBase(nn.Module):

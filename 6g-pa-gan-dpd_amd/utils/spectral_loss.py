@@ -33,6 +33,14 @@ def band_masks(n: int, sample_rate: float, channel_bw: float, adjacent_offset: f
     return m
 
 
+def _check_row_length(n: int, spectrum: bool) -> None:
+    """Row lengths the kernels transform: powers of two in 2..4096 by FFT, any other length up to 8192 by a direct DFT
+    (forward and gradient; e.g. the 4,087 PA outputs of a 4,096-sample slice)."""
+    pow2 = not (n & (n - 1) or n < 2 or n > 4096)
+    if spectrum and not pow2 and (n < 2 or n > 8192):
+        raise NotImplementedError(f"ACPR on the HIP path needs a row length of a power of two in 2..4096 or any length up to 8192, got {n}")
+
+
 class _RowStatsFn(torch.autograd.Function):
     """stats [B, 8] = (sum|p-t|, sum|p-t|^2, sum|t|^2, P_main, P_lower, P_upper, 0, 0) per row."""
 
@@ -43,13 +51,7 @@ class _RowStatsFn(torch.autograd.Function):
         t = L.as_f32(target) if target is not None else None
         B, n = p.shape[0], p.shape[1]
         stats = torch.zeros(B, 8, dtype=torch.float32, device=p.device)
-        pow2 = not (n & (n - 1) or n < 2 or n > 4096)
-        if band is not None and not pow2:
-            # other lengths: direct DFT, forward only (metrics on rows such as the 4,087 PA outputs of a 4,096-sample slice)
-            if n < 2 or n > 8192:
-                raise NotImplementedError(f"ACPR on the HIP path needs a row length of a power of two in 2..4096 or any length up to 8192, got {n}")
-            if pred.requires_grad:
-                raise NotImplementedError(f"ACPR gradients on the HIP path need a power-of-two row length in 2..4096, got {n}")
+        _check_row_length(n, band is not None)
         L.call("dpd_spectral_stats", L.fptr(p), L.fptr(t), B, n, L.fptr(band, torch.uint8), L.fptr(stats), L.stream())
         ctx.save_for_backward(p, t if t is not None else p.new_empty(0), band if band is not None else p.new_empty(0))
         ctx.flags = (t is not None, band is not None)
@@ -78,8 +80,7 @@ class _SpectralTotalFn(torch.autograd.Function):
         L.need_gpu(pred, target, band)
         p, t = L.as_f32(pred), L.as_f32(target)
         B, n = p.shape[0], p.shape[1]
-        if n & (n - 1) or n < 2 or n > 4096:
-            raise NotImplementedError(f"ACPR on the HIP path needs a power-of-two row length in 2..4096, got {n}")
+        _check_row_length(n, True)
         st = L.stream()
         stats = torch.empty(B, 8, dtype=torch.float32, device=p.device)
         sums = torch.empty(8, dtype=torch.float32, device=p.device)
@@ -147,7 +148,9 @@ def compute_nmse(measured: torch.Tensor, reference: torch.Tensor, return_db: boo
     m = measured.reshape(measured.shape[0], -1)
     r = reference.reshape(reference.shape[0], -1)
     if m.shape[1] % 2:
-        raise NotImplementedError("compute_nmse on the HIP path needs an even number of values per row (IQ pairs)")
+        # the kernel sums over IQ pairs: a zero appended to both rows adds nothing to either sum
+        m = torch.nn.functional.pad(m, (0, 1))
+        r = torch.nn.functional.pad(r, (0, 1))
     st = _RowStatsFn.apply(m.reshape(m.shape[0], -1, 2), r.detach().reshape(r.shape[0], -1, 2), None)
     nmse = st[:, 1] / torch.clamp(st[:, 2], min=1e-10)
     return 10 * torch.log10(nmse + 1e-10) if return_db else nmse

@@ -75,6 +75,10 @@ size_t dpd_workspace_bytes(int64_t n_samples);
  * DPD_ERR_SHAPE if S <= 5. */
 int dpd_tap_assembly(const float *iq, int64_t B, int64_t S, float *feat, void *stream);
 
+/* Its adjoint (the reference's MemoryTapAssembly is differentiable torch, models/tdnn_generator.py:158-195):
+ * gfeat [B,S-5,30] -> dx [B,S,2], every point written.  The envelope columns contribute nothing where |x| = 0. */
+int dpd_tap_assembly_backward(const float *iq, int64_t B, int64_t S, const float *gfeat, float *dx, void *stream);
+
 /* Weight preparation shared by every generator call: packs the six parameter tensors into the
  * flat layout; with qat != 0 the weights are per-row fake-quantised (16 bit, scale = rowmax/32767,
  * models/tdnn_generator.py:394-403 with :74-103); biases stay fp32.  absmax[4..6] receive the
