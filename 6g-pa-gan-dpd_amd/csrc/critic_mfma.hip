@@ -240,16 +240,22 @@ DEV float sum_over_groups(float v) {
 // earlier, so the LDS latency of a read is covered by the MFMAs of the group before it.  The fences keep
 // the compiler from sinking those reads down to their first use.
 #define FENCE() __builtin_amdgcn_sched_barrier(0)
-// issue priority of the wave around a burst of matrix instructions (experiment switch CRITIC_SETPRIO)
-#ifndef CRITIC_SETPRIO
-#define CRITIC_SETPRIO 0
+// Issue priority of the wave by the kind of code it is in.  Two waves share a SIMD, and the arbiter serves the older
+// one first: a wave with a matrix instruction waiting for the pipe keeps the vector issue port, so the younger wave's
+// VALU work does not issue beside the older wave's burst of MFMAs (scratch/ubench/cross_wave_nop.hip: a wave of
+// back-to-back bf16 MFMAs and a younger wave of VALU work take the sum of their times, 1.25 + 1.45 -> 2.66 ms; with
+// the VALU wave at a higher priority 1.94 ms whichever is older, which is what the issue port allows).  So a wave runs
+// its stretches without matrix instructions at priority CRITIC_VPRIO and its stretches with them at 0.  s_setprio is
+// a scheduling boundary for the compiler, hence every switch sits next to a fence that is there anyway.
+#ifndef CRITIC_VPRIO
+#define CRITIC_VPRIO 2
 #endif
-#if CRITIC_SETPRIO
-#define PRIO_UP() __builtin_amdgcn_s_setprio(CRITIC_SETPRIO)
-#define PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
+#if CRITIC_VPRIO
+#define PRIO_V() __builtin_amdgcn_s_setprio(CRITIC_VPRIO)
+#define PRIO_M() __builtin_amdgcn_s_setprio(0)
 #else
-#define PRIO_UP()
-#define PRIO_DOWN()
+#define PRIO_V()
+#define PRIO_M()
 #endif
 // experiment hook: ts == NULL in every product build (the code folds away); a timing build passes an
 // array whose slot 15 holds the last stamp
@@ -329,24 +335,58 @@ DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { asm volatile("" : "+v"(c) : "v"
 #else
 DEV f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 #endif
-// c + a x b to fp32 accuracy: two chains of three products each, small terms first
+// c + a x b to fp32 accuracy, small terms first.  CRITIC_ONE_CHAIN (default): the six products of a tile go into one
+// accumulator, in rising order of magnitude -- the matrix pipe runs a dependent accumulation chain at the rate of
+// independent ones, so a second accumulator per tile only costs its registers and the additions that merge it.
+// CRITIC_ONE_CHAIN = 0: two chains of three products each (lo: mm, lh, hl; hi: mh, hm, hh), merged by the caller.
+#ifndef CRITIC_ONE_CHAIN
+#define CRITIC_ONE_CHAIN 1
+#endif
 DEV void mfma6(f32x4 &lo, f32x4 &hi, const B3 &a, const B3 &b) {
-    PRIO_UP();
+#if CRITIC_ONE_CHAIN
+    hi = mfma_bf(a.m, b.m, hi);
+    hi = mfma_bf(a.l, b.h, hi);
+    hi = mfma_bf(a.h, b.l, hi);
+    hi = mfma_bf(a.m, b.h, hi);
+    hi = mfma_bf(a.h, b.m, hi);
+    hi = mfma_bf(a.h, b.h, hi);
+#else
     lo = mfma_bf(a.m, b.m, lo);
     hi = mfma_bf(a.m, b.h, hi);
     lo = mfma_bf(a.l, b.h, lo);
     hi = mfma_bf(a.h, b.m, hi);
     lo = mfma_bf(a.h, b.l, lo);
     hi = mfma_bf(a.h, b.h, hi);
-    PRIO_DOWN();
+#endif
+}
+// two tiles that share the right operand, their chains interleaved
+DEV void mfma6x2(f32x4 &lo0, f32x4 &hi0, f32x4 &lo1, f32x4 &hi1, const B3 &a0, const B3 &a1, const B3 &b) {
+#if CRITIC_ONE_CHAIN
+    hi0 = mfma_bf(a0.m, b.m, hi0);
+    hi1 = mfma_bf(a1.m, b.m, hi1);
+    hi0 = mfma_bf(a0.l, b.h, hi0);
+    hi1 = mfma_bf(a1.l, b.h, hi1);
+    hi0 = mfma_bf(a0.h, b.l, hi0);
+    hi1 = mfma_bf(a1.h, b.l, hi1);
+    hi0 = mfma_bf(a0.m, b.h, hi0);
+    hi1 = mfma_bf(a1.m, b.h, hi1);
+    hi0 = mfma_bf(a0.h, b.m, hi0);
+    hi1 = mfma_bf(a1.h, b.m, hi1);
+    hi0 = mfma_bf(a0.h, b.h, hi0);
+    hi1 = mfma_bf(a1.h, b.h, hi1);
+#else
+    mfma6(lo0, hi0, a0, b);
+    mfma6(lo1, hi1, a1, b);
+#endif
 }
 
 struct FrontOps {      // FC1 weights and accumulator start (b1), FC2 accumulator start (b2), FC2 weights of the first k-step
     f32x4 a1, b1[4], b2[2];
     B3 w[2];
 };
-struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 for the VALU last layer
+struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 and b4 for the VALU last layer
     f32x4 b3, w4;
+    float b4;          // read with the other operands, one MFMA group ahead: a read at its use would expose the LDS latency
     B3 w;
 };
 struct TopOps {        // W3^T, 16-row tile u: [h|l] in t[2u], [h|m] in t[2u + 1]
@@ -367,6 +407,7 @@ DEV void load_ops(FrontOps &o, const float *img, int lane) {
 DEV void load_ops(Fc3Ops &o, const float *img, int lane) {
     o.b3 = quad(img, Q_B3, lane);
     o.w4 = quad(img, Q_W4, lane);
+    o.b4 = img[(Q_B4 * 64 + lane) * 4];
     load_b3(o.w, img, QB_A3, lane);
 }
 DEV void load_ops(TopOps &o, const float *img, int lane) {
@@ -399,9 +440,9 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], const B3 (&w)[2], f32x
     split8(b, src[0], src[1]);
     keep(0, b);
     FENCE();
+    PRIO_M();
     f32x4 y0 = {0.f, 0.f, 0.f, 0.f}, y1 = {0.f, 0.f, 0.f, 0.f};
-    mfma6(y0, z0, w[0], b);
-    mfma6(y1, z1, w[1], b);
+    mfma6x2(y0, z0, y1, z1, w[0], w[1], b);
     if (ACT) {
         act4<BITS>(src[2], slope, src[2], m[2], bits, 8);
         act4<BITS>(src[3], slope, src[3], m[3], bits, 12);
@@ -413,11 +454,13 @@ DEV void fc2_block(f32x4 &z0, f32x4 &z1, f32x4 (&src)[4], const B3 (&w)[2], f32x
     FENCE();
     pre();
     FENCE();
-    mfma6(y0, z0, n[0], b2);
-    mfma6(y1, z1, n[1], b2);
+    mfma6x2(y0, z0, y1, z1, n[0], n[1], b2);
+    PRIO_V();
     FENCE();
+#if !CRITIC_ONE_CHAIN
     z0 += y0;
     z1 += y1;
+#endif
     TS(3)
 }
 
@@ -443,8 +486,14 @@ DEV f32x4 fc3_product(const f32x4 &x0, const f32x4 &x1, const B3 &w, f32x4 start
     split8(b, x0, x1);
     keep(b);
     f32x4 lo = {0.f, 0.f, 0.f, 0.f};
+    PRIO_M();
     mfma6(lo, start, w, b);
+    PRIO_V();
+#if CRITIC_ONE_CHAIN
+    return start;
+#else
     return start + lo;
+#endif
 }
 // FC3 and the last layer (16 -> 1), which runs on the VALU: four FMAs per lane and a sum over the lane groups
 // SCORE = false: the caller wants the activations and masks only (the gradient penalty)
@@ -462,7 +511,7 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
     float s = o.w4[0] * a.h3[0];
 #pragma unroll
     for (int r = 1; r < 4; ++r) s = __builtin_fmaf(o.w4[r], a.h3[r], s);
-    a.score = sum_over_groups(s) + img[(Q_B4 * 64 + lane) * 4];
+    a.score = sum_over_groups(s) + o.b4;
     TS(9)
 }
 
@@ -496,6 +545,7 @@ DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], B3 &sd2, con
     const bf16x8 b_mh = __builtin_bit_cast(bf16x8, u32x4{bm[0], bm[1], bh[0], bh[1]});
     const bf16x8 b_hm = __builtin_bit_cast(bf16x8, u32x4{bh[0], bh[1], bm[0], bm[1]});
     FENCE();
+    PRIO_M();
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = {0.f, 0.f, 0.f, 0.f};
     e0 = mfma_bf(o.t[0], b_lh, e0);
     e0 = mfma_bf(o.t[1], b_mh, e0);
@@ -516,6 +566,7 @@ DEV void chain_top(f32x4 top, const f32x4 (&m2)[2], f32x4 (&d2)[2], B3 &sd2, con
     sd2.h = __builtin_bit_cast(bf16x8, u32x4{h[0], h[1], h[2], h[3]});
     sd2.m = __builtin_bit_cast(bf16x8, u32x4{m[0], m[1], m[2], m[3]});
     sd2.l = __builtin_bit_cast(bf16x8, u32x4{l[0], l[1], l[2], l[3]});
+    PRIO_V();
 }
 // b: the three-way split of d2 (from chain_top).  pre() runs before the second half, whose MFMAs have the masking
 // of the first half's result beside them.
@@ -527,24 +578,31 @@ DEV void chain_bottom(const float *img, int lane, const f32x4 (&)[2], const B3 &
     load_b3(w2[1], img, QB_A2T + 9, lane);
     keep(b);
     FENCE();
+    PRIO_M();          // stays: the caller's outer products follow (or it switches back itself)
     f32x4 f[4], flo[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
         f[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         flo[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    mfma6(flo[0], f[0], o.w[0], b);
-    mfma6(flo[1], f[1], o.w[1], b);
+    mfma6x2(flo[0], f[0], flo[1], f[1], o.w[0], o.w[1], b);
     FENCE();
     pre();
     FENCE();
-    mfma6(flo[2], f[2], w2[0], b);
-    mfma6(flo[3], f[3], w2[1], b);
+    mfma6x2(flo[2], f[2], flo[3], f[3], w2[0], w2[1], b);
+#if CRITIC_ONE_CHAIN
+    d1[0] = f[0] * m1[0];
+    d1[1] = f[1] * m1[1];
+    FENCE();
+    d1[2] = f[2] * m1[2];
+    d1[3] = f[3] * m1[3];
+#else
     d1[0] = (f[0] + flo[0]) * m1[0];
     d1[1] = (f[1] + flo[1]) * m1[1];
     FENCE();
     d1[2] = (f[2] + flo[2]) * m1[2];
     d1[3] = (f[3] + flo[3]) * m1[3];
+#endif
 }
 #else
 struct B3 {};          // (the split terms exist only in the bf16 build)
@@ -558,8 +616,9 @@ struct NoOp {
 struct FrontOps {      // FC1 weights and accumulator start (b1), FC2 accumulator start (b2), first FC2 weight pair
     f32x4 a1, b1[4], b2[2], w0, w1;
 };
-struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 for the VALU last layer
+struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 and b4 for the VALU last layer
     f32x4 b3, w30, w31, w4;
+    float b4;
 };
 struct TopOps {        // W3^T
     f32x4 t0, t1;
@@ -581,6 +640,7 @@ DEV void load_ops(Fc3Ops &o, const float *img, int lane) {
     o.w30 = quad(img, Q_A3, lane);
     o.w31 = quad(img, Q_A3 + 1, lane);
     o.w4 = quad(img, Q_W4, lane);
+    o.b4 = img[(Q_B4 * 64 + lane) * 4];
 }
 DEV void load_ops(TopOps &o, const float *img, int lane) {
     o.t0 = quad(img, Q_A3T, lane);
@@ -655,7 +715,7 @@ DEV void forward_back(Acts &a, const float *img, int lane, float slope, const Fc
     float s = o.w4[0] * a.h3[0];
 #pragma unroll
     for (int r = 1; r < 4; ++r) s = __builtin_fmaf(o.w4[r], a.h3[r], s);
-    a.score = sum_over_groups(s) + img[(Q_B4 * 64 + lane) * 4];
+    a.score = sum_over_groups(s) + o.b4;
     TS(9)
 }
 
@@ -782,8 +842,10 @@ DEV void make_addr(Addr &ad, char *wb, int j, int g) {
         ad.tr = (lds_char *)(wb + 64 * row + 16 * (p ^ ((row >> 1) & 3)));
         ad.tr2 = ad.tr;
         ad.tr3 = ad.tr;
-        asm("" : "+v"(ad.tr2));
-        asm("" : "+v"(ad.tr3));
+        // (volatile: two identical plain asm statements on the same input are one value to the optimiser, and the
+        // reads through tr2 and tr3 would merge again)
+        asm volatile("" : "+v"(ad.tr2));
+        asm volatile("" : "+v"(ad.tr3));
     }
 #else
     ad.wl32 = wb + 4 * (LEFT_W + j * P32 + ((4 * g) ^ swz(j)));
@@ -895,14 +957,12 @@ DEV void outer3(f32x4 &acc, const OpL &a, const OpR &b) {
 }
 // both right tiles against one left tile, the two accumulator chains interleaved
 DEV void outer3x2(f32x4 &acc0, f32x4 &acc1, const OpL &a, const OpR &b0, const OpR &b1) {
-    PRIO_UP();
     acc0 = mfma_bf(a.hl, b0.lh, acc0);
     acc1 = mfma_bf(a.hl, b1.lh, acc1);
     acc0 = mfma_bf(a.hm, b0.mh, acc0);
     acc1 = mfma_bf(a.hm, b1.mh, acc1);
     acc0 = mfma_bf(a.hm, b0.hm, acc0);
     acc1 = mfma_bf(a.hm, b1.hm, acc1);
-    PRIO_DOWN();
 }
 #else
 DEV void park_p2(const Addr &ad, const f32x4 (&left)[4], const f32x4 (&right)[2]) {
@@ -1120,6 +1180,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__r
                                                                 float *__restrict__ score, float *__restrict__ part) {
     __shared__ __attribute__((aligned(16))) float lds[IMG_WORDS];
     build_image(lds, wb);
+    PRIO_V();
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     const int64_t ntiles = (N + 15) >> 4;
@@ -1182,6 +1243,7 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
     // that variant is gone)
     extern __shared__ __attribute__((aligned(16))) float lds[];   // WGRAD: LDS_WORDS (> 64 KiB), else IMG_WORDS
     build_image(lds, wb);
+    PRIO_V();
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + (WGRAD ? wave * WAVE_WORDS : 0));
@@ -1248,6 +1310,9 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
         in_next = fetch_in(tile);
         gs_next = fetch_gs(tile);
         Acts a;
+#ifdef ABL_STAGGER     // experiment (fixed tile order, equal tile counts only): the two waves of a SIMD half a tile apart
+        if (WGRAD && wave < WG_WAVES / 2) __builtin_amdgcn_s_barrier();
+#endif
 #ifdef ABL_TIMING
 #define STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long now = __builtin_readcyclecounter(); tacc[k] += now - tlast; tlast = now; __builtin_amdgcn_sched_barrier(0); }
         STAMP(0)
@@ -1283,6 +1348,9 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
             if (WGRAD) park_b3(ad, S_H2, b);     // after read_p1: the slots lie inside the p1 tile
         });
         STAMP(1)
+#ifdef ABL_STAGGER
+        if (WGRAD && wave >= WG_WAVES / 2) __builtin_amdgcn_s_barrier();
+#endif
         ssum += (valid && g == 0) ? a.score : 0.f;
         const f32x4 (&m1)[4] = a.m1;
         const f32x4 (&m2)[2] = a.m2;
@@ -1325,10 +1393,15 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
             if (WGRAD) park_b3(ad, S_D2, b);     // the h2 slots: their reads are issued
         });
         STAMP(2)
-        load_ops(front, lds, lane);          // next tile
-        FENCE();
+        if (!WGRAD) {
+            PRIO_V();
+            load_ops(front, lds, lane);      // next tile
+            FENCE();
+        }
         if (WGRAD) {
-            // (the fences keep every read one MFMA group ahead of its use)
+            // (the fences keep every read one MFMA group ahead of its use; the next tile's operands are read behind the
+            // last of the transposing reads -- LDS reads return in order, and thirteen 16-byte reads in front of a
+            // group's factors were a wait in front of its MFMAs)
             read_pair_op(h1l[1], ad, S_H1, 1);
             FENCE();
             outer3x2(ac.p2[0][0], ac.p2[0][1], h1l[0], d2r[0], d2r[1]);
@@ -1338,10 +1411,12 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
             outer3x2(ac.p2[1][0], ac.p2[1][1], h1l[1], d2r[0], d2r[1]);
             FENCE();
             read_pair_op(h1l[1], ad, S_H1 + 3 * SLOT_B, 1);
+            load_ops(front, lds, lane);      // next tile
             FENCE();
             outer3x2(ac.p2[2][0], ac.p2[2][1], h1l[0], d2r[0], d2r[1]);
             FENCE();
             outer3x2(ac.p2[3][0], ac.p2[3][1], h1l[1], d2r[0], d2r[1]);
+            PRIO_V();
             __builtin_amdgcn_wave_barrier();
             STAMP(4)
         }
@@ -1481,6 +1556,7 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
                                                           float *__restrict__ tile_sq, unsigned *__restrict__ queue) {
     __shared__ __attribute__((aligned(16))) float lds[IMG_WORDS];
     build_image(lds, wb);
+    PRIO_V();
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     const f32x4 w4 = quad(lds, Q_W4, lane);
@@ -1537,6 +1613,7 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         B3 sv2;
         chain_top(v3, m2, v2, sv2, top, [&] { load_ops(bot, lds, lane); });
         chain_bottom(lds, lane, v2, sv2, m1, v1, bot, [&] { load_ops(ino, lds, lane); });
+        PRIO_V();
         load_ops(front, lds, lane);          // next tile
         FENCE();
         float g0, g1;
@@ -1596,6 +1673,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
                                                           float *__restrict__ slab, unsigned *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // LDS_WORDS
     build_image(lds, wb);
+    PRIO_V();
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + wave * WAVE_WORDS);
@@ -1716,9 +1794,8 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
             read_pair_op(du1l[0], ad, S_H1, 0);
             __builtin_amdgcn_wave_barrier();
         }, [&](const B3 &b) { park_b3(ad, S_D2, b); });      // the du2 slots: their reads are issued
-        load_ops(front, lds, lane);           // next tile
-        FENCE();
-        // (the fences keep every read one MFMA group ahead of its use)
+        // (the fences keep every read one MFMA group ahead of its use; the next tile's operands behind the last
+        // transposing read, see k_critic_bwd_mfma)
         read_pair_op(du1l[1], ad, S_H1, 1);
         FENCE();
         outer3x2(ac.p2[0][0], ac.p2[0][1], du1l[0], v2r[0], v2r[1]);
@@ -1728,10 +1805,12 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         outer3x2(ac.p2[1][0], ac.p2[1][1], du1l[1], v2r[0], v2r[1]);
         FENCE();
         read_pair_op(du1l[1], ad, S_H1 + 3 * SLOT_B, 1);
+        load_ops(front, lds, lane);           // next tile
         FENCE();
         outer3x2(ac.p2[2][0], ac.p2[2][1], du1l[0], v2r[0], v2r[1]);
         FENCE();
         outer3x2(ac.p2[3][0], ac.p2[3][1], du1l[1], v2r[0], v2r[1]);
+        PRIO_V();
         __builtin_amdgcn_wave_barrier();
         // gh tile: column g (< 2) of row j
         if (g < 2) *reinterpret_cast<float *>(ad.cst) = ghb;
@@ -1820,6 +1899,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
                                                               unsigned *__restrict__ queue) {
     extern __shared__ __attribute__((aligned(16))) float lds[];   // LDS_WORDS
     build_image(lds, wb);
+    PRIO_V();
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the tile walk then runs on the scalar unit
     char *wbuf = reinterpret_cast<char *>(lds + IMG_WORDS + wave * WAVE_WORDS);
@@ -1890,6 +1970,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
                   [&](const unsigned (&bh)[2], const unsigned (&bm)[2], const unsigned (&bl)[2]) { park_single(ad, S_D3, bh, bm, bl); });
         chain_bottom(lds, lane, v2, sv2, m1, v1, bot, [&] { load_ops(ino, lds, lane); },
                      [&](const B3 &b) { park_b3(ad, S_D2, b); });      // after read_p1: inside the p1 tile
+        PRIO_V();
         float g0, g1;
         to_input(v1, g0, g1, ino);
         if (!valid) { g0 = 0.f; g1 = 0.f; }
@@ -1917,6 +1998,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
         read_pair_op(du1l[0], ad, S_H1, 0);
         read_pair_op(du1l[1], ad, S_H1, 1);
         FENCE();
+        PRIO_M();
         outer3x2(ac.p2[0][0], ac.p2[0][1], du1l[0], v2r[0], v2r[1]);
         FENCE();
         read_pair_op(du1l[0], ad, S_H1 + 3 * SLOT_B, 0);
@@ -1928,6 +2010,7 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
         outer3x2(ac.p2[2][0], ac.p2[2][1], du1l[0], v2r[0], v2r[1]);
         FENCE();
         outer3x2(ac.p2[3][0], ac.p2[3][1], du1l[1], v2r[0], v2r[1]);
+        PRIO_V();
         __builtin_amdgcn_wave_barrier();
         f32x4 du2[2] = {z0 * m2[0], z1 * m2[1]};
         FENCE();
@@ -1942,12 +2025,14 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
         dw4 += dv3 * m3;
         load_ops(front, lds, lane);           // next tile
         // p3 = du2 x v3
+        PRIO_M();
         ac.p3[0] = mfma_bf(du2l[0].hl, v3r.lh, ac.p3[0]);
         ac.p3[1] = mfma_bf(du2l[1].hl, v3r.lh, ac.p3[1]);
         ac.p3[0] = mfma_bf(du2l[0].hm, v3r.mh, ac.p3[0]);
         ac.p3[1] = mfma_bf(du2l[1].hm, v3r.mh, ac.p3[1]);
         ac.p3[0] = mfma_bf(du2l[0].hm, v3r.hm, ac.p3[0]);
         ac.p3[1] = mfma_bf(du2l[1].hm, v3r.hm, ac.p3[1]);
+        PRIO_V();
         __builtin_amdgcn_wave_barrier();
         // p1 = v1 x g: the g tile (column g < 2 of row j) and v1; runs beside the next tile's forward
         if (g < 2) *reinterpret_cast<float *>(ad.cst) = ghb;

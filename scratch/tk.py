@@ -20,6 +20,9 @@ Lr = S - 5
 N = B * Lr
 name = os.path.basename(os.environ.get("DPD_HIP_LIBRARY", "product"))
 st = L.stream()
+for kv in os.environ.get("DPD_OPTS", "").split():      # library options for this run, e.g. DPD_OPTS="critic_deterministic=1"
+    k, v = kv.split("=")
+    L.call("dpd_set_option", k.encode(), int(v))
 iq = ofdm_rows(B, S, seed=1234, device=dev)
 tgt = iq[:, 5:, :].contiguous()
 
