@@ -42,6 +42,9 @@ PROTOTYPES = {
     "dpd_pa_add_noise": [c_p, c_l, c_l, c_p, c_f, c_p, c_p, ctypes.c_uint64, c_p, c_p, c_sz, c_p],
     "dpd_critic_sn_forward": [c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p],
     "dpd_critic_sn_backward": [c_p, c_p, c_p, c_p, c_p, c_p],
+    "dpd_critic_sn_forward3": [c_p, c_p, c_p, c_p, c_i, c_f, c_p, c_p, c_p, c_p],
+    "dpd_critic_sn_backward3": [c_p, c_p, c_p, c_p, c_f, c_p, c_p],
+    "dpd_qat_observe": [c_p, c_p, c_i, c_f, c_i, c_i, c_p],
     "dpd_critic_forward": [c_p, c_p, c_l, c_p, c_f, c_p, c_p, c_p],
     "dpd_critic_backward": [c_p, c_p, c_l, c_p, c_f, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p],
     "dpd_critic_gp": [c_p, c_p, c_p, c_p, c_l, c_l, c_p, c_f, c_p, c_p, c_p, c_p, c_sz, c_p],

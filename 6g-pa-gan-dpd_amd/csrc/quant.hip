@@ -86,6 +86,20 @@ __global__ __launch_bounds__(256) void k_qlinear_gw(const float *__restrict__ gy
     }
 }
 
+// EMA update of n running scales from n abs-max values, `times` times over (FakeQuantizeModule.observe,
+// models/tdnn_generator.py:121-130: scale = clamp(absmax, 1e-8) / q_max; running = (1 - momentum) * running +
+// momentum * scale, every product and the sum rounded separately as the element-wise tensor arithmetic does)
+__global__ __launch_bounds__(64) void k_qat_observe(const float *__restrict__ absmax, float *__restrict__ running, int n,
+                                                    float keep, float momentum, float q_max, int times) {
+    const int i = threadIdx.x;
+    if (i >= n) return;
+    const float scale = fmaxf(absmax[i], 1e-8f) / q_max;
+    const float add = momentum * scale;
+    float r = running[i];
+    for (int k = 0; k < times; ++k) r = keep * r + add;
+    running[i] = r;
+}
+
 }  // namespace
 
 static QRange qrange_of(float scale, int bits, int is_signed) {
@@ -157,6 +171,19 @@ extern "C" int dpd_fake_quantize_dynamic(const float *x, int64_t rows, int64_t c
     DPD_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_row_fq, dim3(gx, (unsigned)rows), dim3(256), 0, st, x, cols,
                        (float)((1 << (n_bits - 1)) - 1), absmax_out, out);
+    DPD_LAUNCH_CHECK();
+    return DPD_OK;
+}
+
+extern "C" int dpd_qat_observe(const float *absmax, float *running, int n, float momentum, int n_bits, int times,
+                               void *stream) {
+    DPD_REQUIRE(absmax && running, DPD_ERR_INVALID_ARG, "qat_observe: null pointer");
+    DPD_REQUIRE(n >= 1 && n <= 64 && times >= 0, DPD_ERR_INVALID_ARG, "qat_observe: n %d not in 1..64 or times %d < 0", n, times);
+    DPD_REQUIRE(n_bits >= 2 && n_bits <= 24, DPD_ERR_INVALID_ARG, "qat_observe: n_bits %d", n_bits);
+    if (times == 0) return DPD_OK;
+    // (1 - momentum) is formed in double and rounded once, as the host language does before it meets the tensor
+    hipLaunchKernelGGL(k_qat_observe, dim3(1), dim3(64), 0, as_stream(stream), absmax, running, n,
+                       (float)(1.0 - (double)momentum), momentum, (float)((1 << (n_bits - 1)) - 1), times);
     DPD_LAUNCH_CHECK();
     return DPD_OK;
 }

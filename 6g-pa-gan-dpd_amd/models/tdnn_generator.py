@@ -289,29 +289,34 @@ class TDNNGeneratorQAT(_GeneratorBase):
         self.repeat_observation()
         return out
 
-    def repeat_observation(self):
-        """Advance the running-scale buffers as one more training-mode forward on the same input and
+    def repeat_observation(self, times: int = 1):
+        """Advance the running-scale buffers as `times` more training-mode forwards on the same input and
         weights would (used when a caller reuses the output instead of recomputing it)."""
         absmax = getattr(self, "_last_absmax", None)
-        if absmax is not None:
-            self.observe_all(absmax)
+        if absmax is not None and times > 0:
+            self.observe_all(absmax, times)
 
-    def observe_all(self, absmax: torch.Tensor):
+    def observe_all(self, absmax: torch.Tensor, times: int = 1):
         """The EMA update of every quantiser's running scale from the abs-max vector of a forward (order: features,
-        act1, act2, output, W1, W2, W3), all seven at once: the arithmetic of FakeQuantizeModule.observe element by
-        element, in six launches instead of thirty-five.  The buffers become views of one seven-element tensor."""
+        act1, act2, output, W1, W2, W3), all seven in one launch (dpd_qat_observe: the arithmetic of
+        FakeQuantizeModule.observe element by element, `times` times over).  The buffers become views of one
+        seven-element tensor, which the kernel updates in place."""
         mods = [getattr(self, name) for name in self.ACT_QUANT + self.WEIGHT_QUANT]
         m0 = mods[0]
-        if any(m.n_bits != m0.n_bits or m.momentum != m0.momentum for m in mods):
-            for i, m in enumerate(mods):
-                m.observe(absmax[i])
+        if any(m.n_bits != m0.n_bits or m.momentum != m0.momentum for m in mods) or not absmax.is_cuda:
+            for _ in range(times):
+                for i, m in enumerate(mods):
+                    m.observe(absmax[i])
             return
-        q_max = 2 ** (m0.n_bits - 1) - 1
-        scale = torch.clamp(absmax[:len(mods)], min=1e-8) / q_max
-        rs = torch.stack([m.running_scale for m in mods])
-        rs = (1 - m0.momentum) * rs + m0.momentum * scale
-        for m, r in zip(mods, rs.unbind(0)):
-            m.running_scale = r
+        rs = getattr(self, "_running_all", None)
+        bound = rs is not None and all(m.running_scale.data_ptr() == rs[i].data_ptr() for i, m in enumerate(mods))
+        if not bound:          # first use, or the buffers were replaced (load_state_dict copies in place and keeps them)
+            rs = torch.stack([m.running_scale.detach().to(torch.float32) for m in mods]).to(absmax.device)
+            self._running_all = rs
+            for m, r in zip(mods, rs.unbind(0)):
+                m.running_scale = r
+        L.call("dpd_qat_observe", L.fptr(L.as_f32(absmax)), L.fptr(rs), len(mods), float(m0.momentum), int(m0.n_bits),
+               int(times), L.stream())
 
     def get_quantized_weights(self) -> Dict[str, torch.Tensor]:
         weights = {}

@@ -21,10 +21,17 @@ import torch.distributed as dist
 
 def _all_reduce(t: torch.Tensor, op, group=None) -> torch.Tensor:
     """all_reduce in place.  RCCL (backend "nccl") reduces device tensors directly.  Under gloo (CPU tests and the
-    one-GPU rehearsal of the multi-rank path) a device tensor is reduced through a host copy: gloo's own handling of
-    device tensors is not dependable on ROCm builds (observed: two ranks on one GPU stall inside all_reduce after a
-    few dozen calls), and the payloads here are a few kilobytes."""
-    mode = os.environ.get("DPD_GLOO_DEVICE_TENSORS", "0")     # experiment switch, see below
+    one-GPU rehearsal of the multi-rank path) a device tensor is reduced through a host copy, and the payloads here
+    are a few kilobytes.
+
+    Why: handed device tensors, gloo stalls when the work that produces the tensor is still in flight on the stream.
+    Two ranks on one GPU, Stage-2 steps, DPD_GLOO_DEVICE_TENSORS=1: after a few dozen collectives both ranks sit in
+    the SAME dist.all_reduce (the gradient all-reduce of the critic update; stack dump of both ranks after 45 s), so
+    the ranks agree on the order of collectives and the wait is inside gloo's device path.  The same run with a
+    torch.cuda.synchronize() in front of every all_reduce (DPD_GLOO_DEVICE_TENSORS=2) completes.  The host copy below
+    contains that synchronisation, so it is the fix and not a cover: nothing of ours is left in flight when gloo gets
+    the data.  RCCL orders its kernels on the stream itself and is not affected."""
+    mode = os.environ.get("DPD_GLOO_DEVICE_TENSORS", "0")     # experiment switch: 1 = device tensors to gloo, 2 = after a synchronise
     if t.is_cuda and mode == "2":
         torch.cuda.synchronize()
     if t.is_cuda and dist.get_backend(group) == "gloo" and mode == "0":

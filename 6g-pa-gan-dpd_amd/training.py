@@ -125,9 +125,9 @@ class CriticUpdate:
         n = L.CRITIC_NPARAM
         f = dict(dtype=torch.float32, device=dev)
         self.wb, self.uv, self.sigma = torch.empty(3, n, **f), torch.empty(3, 229, **f), torch.empty(3, 4, **f)
-        self.gwb, self.gpar = torch.empty(3, n, **f), torch.empty(3, n, **f)
+        self.gwb = torch.empty(3, n, **f)
         self.total = torch.zeros(n, **f)
-        self.sums = torch.zeros(4, **f)                # sum D(real), sum D(fake), gradient penalty, unused (stays 0)
+        self.sums = torch.zeros(16, 4, **f)            # per update of a step: sum D(real), sum D(fake), gradient penalty, 0
         self.rownorm = None
         self.coef, self.coef_n = None, None
 
@@ -147,7 +147,8 @@ class CriticUpdate:
             if p.grad is None or p.grad.data_ptr() != g.data_ptr():
                 p.grad = g.view_as(p)
 
-    def __call__(self, real, fake, cond, alpha=None) -> torch.Tensor:
+    def __call__(self, real, fake, cond, alpha=None, slot: int = 0) -> torch.Tensor:
+        """One update; the three sums it leaves go to row `slot` of self.sums (shares() turns the rows into losses)."""
         from .models.discriminator import _ptr_array
         disc, dp = self.disc, self.dp
         B = real.shape[0]
@@ -165,33 +166,38 @@ class CriticUpdate:
             alpha = torch.rand(B, 1, device=dev)
         if self.rownorm is None or self.rownorm.numel() != B:
             self.rownorm = torch.empty(B, dtype=torch.float32, device=dev)
+        if slot >= self.sums.shape[0]:
+            self.sums = torch.zeros(2 * slot + 2, 4, dtype=torch.float32, device=dev)
+        sums = self.sums[slot]
         cond_c = L.as_f32(cond)
+        # the three evaluations' spectral normalisation (three successive power iterations, in the reference's order
+        # real, fake, interpolate) in one launch: nothing between them touches the weights or u, v
+        L.call("dpd_critic_sn_forward3", ws, bs, us, vs, power, eps, L.fptr(self.wb), L.fptr(self.uv), L.fptr(self.sigma), st)
         # d_loss = -(mean D(real) - mean D(fake)); every rank contributes its shard's mean / world
         for k, (x, sign) in enumerate(((real, -1.0), (fake, 1.0))):
-            L.call("dpd_critic_sn_forward", ws, bs, us, vs, power, eps, L.fptr(self.wb[k]), L.fptr(self.uv[k]),
-                   L.fptr(self.sigma[k]), st)
             L.call("dpd_critic_backward", L.fptr(L.as_f32(x)), L.fptr(cond_c), N, L.fptr(self.wb[k]), slope, L.c_p(0),
-                   sign / (N * dp.world), L.fptr(self.gwb[k]), L.c_p(0), L.fptr(self.sums[k:k + 1]), wsp, wsn, st)
-            L.call("dpd_critic_sn_backward", ws, L.fptr(self.gwb[k]), L.fptr(self.uv[k]), L.fptr(self.sigma[k]),
-                   L.fptr(self.gpar[k]), st)
-        L.call("dpd_critic_sn_forward", ws, bs, us, vs, power, eps, L.fptr(self.wb[2]), L.fptr(self.uv[2]),
-               L.fptr(self.sigma[2]), st)
+                   sign / (N * dp.world), L.fptr(self.gwb[k]), L.c_p(0), L.fptr(sums[k:k + 1]), wsp, wsn, st)
         L.call("dpd_critic_gp", L.fptr(L.as_f32(real)), L.fptr(L.as_f32(fake)), L.fptr(cond_c),
-               L.fptr(L.as_f32(alpha).reshape(-1)), B, Lrow, L.fptr(self.wb[2]), slope, L.fptr(self.sums[2:3]),
+               L.fptr(L.as_f32(alpha).reshape(-1)), B, Lrow, L.fptr(self.wb[2]), slope, L.fptr(sums[2:3]),
                L.fptr(self.rownorm), L.fptr(self.gwb[2]), wsp, wsn, st)
-        L.call("dpd_critic_sn_backward", ws, L.fptr(self.gwb[2]), L.fptr(self.uv[2]), L.fptr(self.sigma[2]),
-               L.fptr(self.gpar[2]), st)
-        torch.add(self.gpar[0], self.gpar[1], out=self.total)
-        self.total.add_(self.gpar[2], alpha=self.gp_weight / dp.world)
+        # spectral-norm backward of the three evaluations and their combination (g_real + g_fake) + w * g_penalty
+        L.call("dpd_critic_sn_backward3", ws, L.fptr(self.gwb), L.fptr(self.uv), L.fptr(self.sigma),
+               self.gp_weight / dp.world, L.fptr(self.total), st)
         self._bind_grads()
         dp.sum_(self.total)
         self.opt.step()
-        # this rank's share of the critic loss, (sum D(fake) - sum D(real)) / N + gp_weight * gp, over the number of ranks
-        # (the caller sums the shares of all ranks, once per step): one dot product with the three sums the calls left
+        self._n = N
+        return sums
+
+    def shares(self, n_updates: int) -> torch.Tensor:
+        """This rank's share of the critic loss of updates 0..n_updates-1, (sum D(fake) - sum D(real)) / N +
+        gp_weight * gp, over the number of ranks (the caller sums the shares of all ranks, once per step): one
+        matrix-vector product with the sums the updates left."""
+        N, dp, dev = self._n, self.dp, self.sums.device
         if self.coef is None or self.coef_n != (N, dp.world):
             self.coef = torch.tensor([-1.0 / N, 1.0 / N, self.gp_weight, 0.0], dtype=torch.float32, device=dev) / dp.world
             self.coef_n = (N, dp.world)
-        return torch.dot(self.sums, self.coef)
+        return torch.mv(self.sums[:n_updates], self.coef)
 
 
 class Stage2Step:
@@ -253,13 +259,18 @@ class Stage2Step:
         # running-scale bookkeeping of those forwards has to be repeated.
         fake = gen(iq)
         fake_d = fake.detach()
+        # the running-scale bookkeeping of the n_critic forwards the reference repeats (n_critic - 1 more in the critic
+        # loop, one for the generator update): nothing reads the running scales in between, so all at once
+        if hasattr(gen, "repeat_observation"):
+            gen.repeat_observation(self.n_critic)
+        fast = self.critic_update is not None and target.dim() == 3
+        if alphas is None and fast and self.n_critic > 0:
+            alphas = torch.rand(self.n_critic, iq.shape[0], 1, device=iq.device)      # one launch for the step's draws
         d_shares = []
         for it in range(self.n_critic):
-            if it > 0 and hasattr(gen, "repeat_observation"):
-                gen.repeat_observation()
             alpha = alphas[it] if alphas is not None else None
-            if self.critic_update is not None and target.dim() == 3:
-                d_shares.append(self.critic_update(target, fake_d, cond, alpha))
+            if fast:
+                self.critic_update(target, fake_d, cond, alpha, slot=it)
                 continue
             self.d_opt.zero_grad(set_to_none=True)
             d_total, d_info = self._critic_loss(target, fake_d, cond, alpha)
@@ -268,8 +279,8 @@ class Stage2Step:
             self.d_opt.step()
             d_shares.append(d_total.detach())
         # the critic losses of the step are only reported: one all-reduce for all of them
-        if d_shares:
-            d_all = dp.sum_(torch.stack(d_shares))
+        if self.n_critic > 0:
+            d_all = dp.sum_(self.critic_update.shares(self.n_critic) if fast else torch.stack(d_shares))
             for it in range(self.n_critic):
                 info[f"d_total_{it}"] = d_all[it]
         self.g_opt.zero_grad(set_to_none=True)
@@ -277,8 +288,6 @@ class Stage2Step:
         for p in d_params:
             p.requires_grad_(False)
         try:
-            if hasattr(gen, "repeat_observation"):
-                gen.repeat_observation()
             g_total, g_info = self._generator_loss(fake, target, cond)
             g_total.backward()
         finally:

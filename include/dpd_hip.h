@@ -230,6 +230,17 @@ int dpd_critic_sn_forward(const float *const *w_orig, const float *const *bias, 
 int dpd_critic_sn_backward(const float *const *w_orig, const float *gwb, const float *uv_saved,
                            const float *sigma, float *grads, void *stream);
 
+/* The three evaluations of one critic update (WassersteinLoss.discriminator_loss, models/discriminator.py:204-244:
+ * D(real), D(fake), D(interpolate), each a forward with its own power iteration) in one launch each way:
+ * dpd_critic_sn_forward3 = three successive dpd_critic_sn_forward, evaluation k into wb + k * 2945,
+ * uv_saved + k * 229, sigma + k * 4; dpd_critic_sn_backward3: grads [2945] = (g_0 + g_1) + coef2 * g_2 with g_k
+ * what dpd_critic_sn_backward gives for gwb + k * 2945 and the saved u, v, sigma of evaluation k. */
+int dpd_critic_sn_forward3(const float *const *w_orig, const float *const *bias, float *const *u,
+                           float *const *v, int power_iteration, float eps, float *wb, float *uv_saved,
+                           float *sigma, void *stream);
+int dpd_critic_sn_backward3(const float *const *w_orig, const float *gwb, const float *uv_saved,
+                            const float *sigma, float coef2, float *grads, void *stream);
+
 /* Discriminator.forward (models/discriminator.py:103-136) given the already spectrally
  * normalised weights wb (flat, DPD_CRITIC_NPARAM): score[n] for n < N rows of x [N,2], cond [N,2].
  * score_sum (optional) receives sum_n score[n]. */
@@ -312,6 +323,12 @@ int dpd_quantized_linear_backward(const float *x, const float *w, const float *g
  * is required: it is the reduction scratch and returns the abs-max values. */
 int dpd_fake_quantize_dynamic(const float *x, int64_t rows, int64_t cols, int per_row, int n_bits,
                               float *out, float *absmax_out, void *stream);
+
+/* FakeQuantizeModule.observe (models/tdnn_generator.py:121-130) for n <= 64 quantisers at once, `times` times over
+ * with the same observation: running[i] <- (1 - momentum) * running[i] + momentum * max(absmax[i], 1e-8) / q_max,
+ * q_max = 2^(n_bits-1) - 1 (a caller that reuses one forward for several steps repeats the bookkeeping only). */
+int dpd_qat_observe(const float *absmax, float *running, int n, float momentum, int n_bits, int times,
+                    void *stream);
 
 /* Bit-exact Q8.8 inference: iq int16 Q1.15 [B,S,2] -> out int16 Q1.15 [B,S-5,2].
  * Weights int16 Q1.15 (w1 [32,30], w2 [16,32], w3 [2,16]), biases int16 Q8.8, accumulators Q9.23,
