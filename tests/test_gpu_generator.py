@@ -282,3 +282,32 @@ def test_chain_gradient_wrt_iq_rows(dpd, qat):
     got = torch.cat([p.grad.reshape(-1) for p in (gen.fc1.weight, gen.fc1.bias, gen.fc2.weight, gen.fc2.bias, gen.fc3.weight, gen.fc3.bias)])
     ref = torch.cat([params[k].grad.reshape(-1) for k in og.PARAM_KEYS])
     close(got, ref, rtol=1e-5, atol=(2e-6 if not qat else 5e-6) * float(ref.abs().max()))
+
+
+def test_running_scales_in_one_launch_match_the_module_arithmetic():
+    """dpd_qat_observe (all seven running scales, `times` repeats, one launch) against FakeQuantizeModule.observe
+    applied element by element on the CPU (the reference's arithmetic, models/tdnn_generator.py:121-130)."""
+    from dpd_amd.models import TDNNGeneratorQAT
+    torch.manual_seed(4)
+    gen = TDNNGeneratorQAT().to(DEV).train()
+    absmax = (torch.rand(8, device=DEV) * 3 + 1e-3)
+    absmax[2] = 0.0                                  # below the clamp
+    start = [float(getattr(gen, n).running_scale) for n in gen.ACT_QUANT + gen.WEIGHT_QUANT]
+    gen.observe_all(absmax)
+    gen.observe_all(absmax, times=4)
+    got = torch.stack([getattr(gen, n).running_scale for n in gen.ACT_QUANT + gen.WEIGHT_QUANT]).cpu()
+    a = absmax[:7].cpu()
+    rs = torch.tensor(start, dtype=torch.float32)
+    for _ in range(5):
+        scale = torch.clamp(a, min=1e-8) / 32767
+        rs = (1 - 0.1) * rs + 0.1 * scale
+    close(got, rs.numpy(), rtol=3e-7, atol=0)
+    # the buffers are views of one tensor now and survive a state-dict round trip
+    sd = {k: v.clone() for k, v in gen.state_dict().items()}
+    gen2 = TDNNGeneratorQAT().to(DEV)
+    gen2.load_state_dict(sd)
+    assert torch.equal(gen2.input_quant.running_scale, gen.input_quant.running_scale)
+    gen2.train()
+    gen2.observe_all(absmax)
+    gen.observe_all(absmax)
+    assert torch.equal(gen2.fc3_weight_quant.running_scale, gen.fc3_weight_quant.running_scale)

@@ -362,3 +362,43 @@ def test_mfma_critic_accuracy_against_fp64():
     assert err(out, score.detach()) < 1.5e-6
     assert err(gx, xd.grad) < 1.5e-6
     assert err(grads, ref_g) < 2e-6
+
+
+def test_batched_spectral_norm_equals_three_calls():
+    """dpd_critic_sn_forward3 / _backward3 (one launch for the three evaluations of a critic update) against three
+    dpd_critic_sn_forward / _backward calls: the operands, saved u / v, sigmas and the module's u, v buffers bit for
+    bit; the combined gradient (g_0 + g_1) + c * g_2 to fp32 rounding of the two additions."""
+    from dpd_amd import _lib as L
+    from dpd_amd.models import Discriminator
+    from dpd_amd.models.discriminator import _ptr_array
+    torch.manual_seed(11)
+    st = L.stream()
+
+    def fresh():
+        torch.manual_seed(12)
+        d = Discriminator().to(DEV).train()
+        layers = list(d._layers())
+        ptrs = [_ptr_array([getattr(lin, n) for lin in layers]) for n in ("weight_orig", "bias", "weight_u", "weight_v")]
+        return d, layers, ptrs
+    n = L.CRITIC_NPARAM
+    f = dict(dtype=torch.float32, device=DEV)
+    gwb = torch.randn(3, n, **f)
+    d1, l1, (ws, bs, us, vs) = fresh()
+    wb1, uv1, sg1, g1 = torch.empty(3, n, **f), torch.empty(3, 229, **f), torch.empty(3, 4, **f), torch.empty(3, n, **f)
+    for k in range(3):
+        L.call("dpd_critic_sn_forward", ws, bs, us, vs, 1, 1e-12, L.fptr(wb1[k]), L.fptr(uv1[k]), L.fptr(sg1[k]), st)
+    for k in range(3):
+        L.call("dpd_critic_sn_backward", ws, L.fptr(gwb[k]), L.fptr(uv1[k]), L.fptr(sg1[k]), L.fptr(g1[k]), st)
+    d2, l2, (ws2, bs2, us2, vs2) = fresh()
+    wb2, uv2, sg2, tot = torch.empty(3, n, **f), torch.empty(3, 229, **f), torch.empty(3, 4, **f), torch.empty(n, **f)
+    L.call("dpd_critic_sn_forward3", ws2, bs2, us2, vs2, 1, 1e-12, L.fptr(wb2), L.fptr(uv2), L.fptr(sg2), st)
+    L.call("dpd_critic_sn_backward3", ws2, L.fptr(gwb), L.fptr(uv2), L.fptr(sg2), 2.5, L.fptr(tot), st)
+    assert torch.equal(wb1, wb2) and torch.equal(uv1, uv2) and torch.equal(sg1, sg2)
+    for a, b in zip(l1, l2):
+        assert torch.equal(a.weight_u, b.weight_u) and torch.equal(a.weight_v, b.weight_v)
+    ref = (g1[0].double() + g1[1].double()) + 2.5 * g1[2].double()
+    close(tot, ref.cpu().numpy(), rtol=1e-6, atol=2e-7 * float(ref.abs().max()))
+    # evaluation mode: no power iteration, the three operands are equal and u, v stay
+    u_before = l2[0].weight_u.clone()
+    L.call("dpd_critic_sn_forward3", ws2, bs2, us2, vs2, 0, 1e-12, L.fptr(wb2), L.fptr(uv2), L.fptr(sg2), st)
+    assert torch.equal(wb2[0], wb2[1]) and torch.equal(wb2[1], wb2[2]) and torch.equal(l2[0].weight_u, u_before)
