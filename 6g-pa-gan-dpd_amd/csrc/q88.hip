@@ -430,10 +430,12 @@ __global__ __launch_bounds__(MW * 64, Q88_MFMA_WAVES) void k_q88_mfma(const int 
         }
         if (chunk < n_chunks) fetch(row, pos, fresh);
         __builtin_amdgcn_wave_barrier();
-        int x3h[4] = {0, 0, 0, 0}, x3l[4] = {0, 0, 0, 0};     // FC2 results of the four tiles, as digits
+        // FC2 results of the four tiles, as digits.  All four tiles run for every chunk: past the end of the row their
+        // points are zeros (or what an earlier chunk left in the planes) and their outputs are not stored, which is
+        // cheaper than a guard whose skipped path needs these eight registers zeroed in every chunk.
+        int x3h[4], x3l[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            if (t0 + 16 * c >= L) break;           // wave-uniform
             // ---- FC1 operand
             const int *a = reinterpret_cast<const int *>(qA + 16 * c), *b = reinterpret_cast<const int *>(qB + 16 * c);
             const int *cc = reinterpret_cast<const int *>(qC + 16 * c);
