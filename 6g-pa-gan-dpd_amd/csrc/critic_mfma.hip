@@ -395,19 +395,32 @@ struct TopOps {        // W3^T, 16-row tile u: [h|l] in t[2u], [h|m] in t[2u + 1
 struct BotOps {        // W2^T, row tiles 0 and 1
     B3 w[2];
 };
-DEV void load_ops(FrontOps &o, const float *img, int lane) {
+// The fp32 operands of a tile that are not weights of a matrix product with split terms -- the FC1 weights, the three
+// bias quads that start the accumulators, W4 and b4 -- stay in registers for the life of the wave (CRITIC_RESIDENT, 44
+// registers): an LDS read of 16 bytes per lane costs the SIMD about 15 cycles whoever issues it (measured with extra
+// reads per tile), and these were nine of the forty operand reads of a tile.  load_resident() once, load_ops() per tile.
+#ifndef CRITIC_RESIDENT
+#define CRITIC_RESIDENT 1
+#endif
+DEV void load_resident(FrontOps &o, const float *img, int lane) {
     o.a1 = quad(img, Q_A1, lane);
 #pragma unroll
     for (int t = 0; t < 4; ++t) o.b1[t] = quad(img, Q_B1 + t, lane);
     o.b2[0] = quad(img, Q_B2, lane);
     o.b2[1] = quad(img, Q_B2 + 1, lane);
+}
+DEV void load_ops(FrontOps &o, const float *img, int lane) {
+    if (!CRITIC_RESIDENT) load_resident(o, img, lane);
     load_b3(o.w[0], img, QB_A2, lane);
     load_b3(o.w[1], img, QB_A2 + 6, lane);
 }
-DEV void load_ops(Fc3Ops &o, const float *img, int lane) {
+DEV void load_resident(Fc3Ops &o, const float *img, int lane) {
     o.b3 = quad(img, Q_B3, lane);
     o.w4 = quad(img, Q_W4, lane);
     o.b4 = img[(Q_B4 * 64 + lane) * 4];
+}
+DEV void load_ops(Fc3Ops &o, const float *img, int lane) {
+    if (!CRITIC_RESIDENT) load_resident(o, img, lane);
     load_b3(o.w, img, QB_A3, lane);
 }
 DEV void load_ops(TopOps &o, const float *img, int lane) {
@@ -626,6 +639,7 @@ struct TopOps {        // W3^T
 struct BotOps {        // W2^T, first half (u = 0)
     f32x4 w[4];
 };
+DEV void load_resident(FrontOps &, const float *, int) {}      // (the all-fp32 build reads every operand per tile)
 DEV void load_ops(FrontOps &o, const float *img, int lane) {
     o.a1 = quad(img, Q_A1, lane);
 #pragma unroll
@@ -642,6 +656,7 @@ DEV void load_ops(Fc3Ops &o, const float *img, int lane) {
     o.w4 = quad(img, Q_W4, lane);
     o.b4 = img[(Q_B4 * 64 + lane) * 4];
 }
+DEV void load_resident(Fc3Ops &, const float *, int) {}
 DEV void load_ops(TopOps &o, const float *img, int lane) {
     o.t0 = quad(img, Q_A3T, lane);
     o.t1 = quad(img, Q_A3T + 1, lane);
@@ -1171,6 +1186,17 @@ DEV void abl_extra(float &d0, float &d1, float &d2, float &d3, f32x4 &dm) {
     for (int i = 0; i < ABL_EXTRA_MFMA; ++i) dm = mfma_bf(a, a, dm);
 #endif
 }
+// experiment hook: ABL_EXTRA_LDS extra 16-byte reads of the weight image per tile (results kept alive, not used)
+DEV void abl_extra_lds(const float *img, int lane, f32x4 &sink) {
+#ifdef ABL_EXTRA_LDS
+#pragma unroll
+    for (int i = 0; i < ABL_EXTRA_LDS; ++i) {
+        f32x4 v = quad(img, Q_B1 + (i & 3), lane);
+        asm volatile("" : "+v"(v));
+        sink[i & 3] = v[i & 3];
+    }
+#endif
+}
 // ------------------------------------------------------------------------------------- kernels
 #ifndef NOGRAD_WAVES
 #define NOGRAD_WAVES 2      // measured: 3 waves per SIMD (168 registers, ~35 spilled) is 7% slower on the Stage-2 step
@@ -1199,6 +1225,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__r
     };
     float raw_next = fetch((int64_t)blockIdx.x * WAVES + wave);
     FrontOps front;
+    Fc3Ops o3;
+    load_resident(front, lds, lane);
+    load_resident(o3, lds, lane);
     load_ops(front, lds, lane);
     for (int64_t tile = (int64_t)blockIdx.x * WAVES + wave; tile < ntiles; tile += stride) {
         const int64_t n = tile * 16 + j;
@@ -1206,7 +1235,6 @@ __global__ __launch_bounds__(WAVES * 64) void k_critic_fwd_mfma(const float *__r
         const float in = valid ? raw_next : 0.f;
         raw_next = fetch(tile + stride);
         Acts a;
-        Fc3Ops o3;
         forward_front(a, lds, lane, in, slope, front, [&] { load_ops(o3, lds, lane); });
         forward_back(a, lds, lane, slope, o3, [&] { load_ops(front, lds, lane); });
         if (valid && g == 0) {
@@ -1275,6 +1303,9 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
     unsigned long long tacc[6] = {0}, tlast = clk0;
     unsigned long long fts[16] = {0};
 #endif
+#ifdef ABL_EXTRA_LDS
+    f32x4 abl_sink = {0.f, 0.f, 0.f, 0.f};
+#endif
     const int64_t ntiles = (N + 15) >> 4;
     // the tile's input (and upstream gradient) is loaded one tile ahead
     // (branch-free: clamped index, value selected afterwards -- a load inside a conditional block makes the
@@ -1292,6 +1323,9 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
         return gsrc[(n < N && gscore) ? n : 0];
     };
     FrontOps front;
+    Fc3Ops o3;
+    load_resident(front, lds, lane);
+    load_resident(o3, lds, lane);
     load_ops(front, lds, lane);
 #ifdef ABL_PHASE_SHIFT     // experiment: the second wave of every SIMD starts a fraction of a tile late
     if (WGRAD && wave >= WG_WAVES / 2) __builtin_amdgcn_s_sleep(ABL_PHASE_SHIFT);
@@ -1319,7 +1353,6 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
 #else
 #define STAMP(k)
 #endif
-        Fc3Ops o3;
         TopOps top;
         BotOps bot;
         InOps ino;
@@ -1493,7 +1526,13 @@ __global__ __launch_bounds__((WGRAD ? WG_WAVES : WAVES) * 64, WGRAD ? WG_PER_CU 
 #if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
         abl_extra(abl0, abl1, abl2, abl3, ablm);
 #endif
+#ifdef ABL_EXTRA_LDS
+        abl_extra_lds(lds, lane, abl_sink);
+#endif
     }
+#ifdef ABL_EXTRA_LDS
+    if (abl_sink[0] + abl_sink[1] + abl_sink[2] + abl_sink[3] == 1.2345f) ssum += 1.f;
+#endif
 #if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
     if (abl0 + abl1 + abl2 + abl3 + ablm[0] == 1.2345f) ssum += 1.f;
 #endif
@@ -1581,6 +1620,9 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         return r;
     };
     FrontOps front;
+    Fc3Ops o3;
+    load_resident(front, lds, lane);
+    load_resident(o3, lds, lane);
     load_ops(front, lds, lane);
 #if defined(ABL_EXTRA_VALU) || defined(ABL_EXTRA_MFMA)
     float abl0 = slope, abl1 = slope + 1.f, abl2 = slope + 2.f, abl3 = slope + 3.f;
@@ -1599,7 +1641,6 @@ __global__ __launch_bounds__(WAVES * 64, NOGRAD_WAVES) void k_gp_a_mfma(const fl
         tile_next = tq.tile();
         raw_next = fetch(tile_next);
         Acts a;
-        Fc3Ops o3;
         TopOps top;
         BotOps bot;
         InOps ino;
@@ -1692,6 +1733,9 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
     f32x4 dw4 = {0.f, 0.f, 0.f, 0.f};
     const f32x4 w4 = quad(lds, Q_W4, lane);
     FrontOps front;
+    Fc3Ops o3;
+    load_resident(front, lds, lane);
+    load_resident(o3, lds, lane);
     load_ops(front, lds, lane);
     const int64_t ntiles = (N + 15) >> 4;
     const unsigned tpr = ROW1 ? 1u : (unsigned)(L >> 4);      // tiles per row
@@ -1746,7 +1790,6 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         for (int t = 0; t < 4; ++t) du1[t] = mfma4(front.a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f}) * m1[t];
         // dv2 = W2 du1, du2 = dv2 * D2
         f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
-        Fc3Ops o3;
         TopOps top;
         BotOps bot;
         P1R p1r;
@@ -1931,6 +1974,9 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
         return r;
     };
     FrontOps front;
+    Fc3Ops o3;
+    load_resident(front, lds, lane);
+    load_resident(o3, lds, lane);
     load_ops(front, lds, lane);
     TileQueue tq;
     tq.init(queue, blockIdx.x * WG_WAVES + wave, gridDim.x * WG_WAVES, ntiles, gp_big_unit(tpr));
@@ -1947,7 +1993,6 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
         tile_next = tq.tile();
         raw_next = fetch(tile_next);
         Acts a;
-        Fc3Ops o3;
         TopOps top;
         BotOps bot;
         InOps ino;
