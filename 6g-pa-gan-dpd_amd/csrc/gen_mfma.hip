@@ -88,7 +88,11 @@ DEV void load_chunk_iq(ChunkIQ &c, const float2 *__restrict__ iqrow, int64_t t0,
         if ((rep == 0 || lane < 5) && idx < S) c.p[rep] = iqrow[idx];
     }
 }
+template <bool ASM>
 DEV f32x4 fq16x4(f32x4 v, QS k);
+DEV f32x4 q16x4(f32x4 v, QS k);
+DEV float q16(float v, QS k);
+DEV float digit_word(float q);
 // Derive the five series from the loaded points and park them in LDS.
 template <bool QAT>
 DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
@@ -101,7 +105,7 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
         float e2 = e * e;
         float e4 = e2 * e2;
         if (QAT) {
-            const f32x4 qv = fq16x4(f32x4{v.x, v.y, e, e2}, s0);
+            const f32x4 qv = fq16x4<true>(f32x4{v.x, v.y, e, e2}, s0);
             v.x = qv[0]; v.y = qv[1]; e = qv[2]; e2 = qv[3];
             e4 = fq16(e4, s0);
         }
@@ -114,13 +118,18 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
     }
 }
 // One time point: derive its five series values and park them at position tau of the chunk's series.
-template <bool QAT>
+// DIG (QAT forward on the bf16 matrix cores): a series word holds the two bf16 digits of the quantised integer.
+template <bool QAT, bool DIG = false>
 DEV void commit_point(float *ser, float2 v, int tau, QS s0) {
     float e = sqrtf(v.x * v.x + v.y * v.y);
     float e2 = e * e;
     float e4 = e2 * e2;
-    if (QAT) {
-        const f32x4 qv = fq16x4(f32x4{v.x, v.y, e, e2}, s0);
+    if (DIG) {
+        const f32x4 qv = q16x4(f32x4{v.x, v.y, e, e2}, s0);
+        v.x = digit_word(qv[0]); v.y = digit_word(qv[1]); e = digit_word(qv[2]); e2 = digit_word(qv[3]);
+        e4 = digit_word(q16(e4, s0));
+    } else if (QAT) {
+        const f32x4 qv = fq16x4<true>(f32x4{v.x, v.y, e, e2}, s0);
         v.x = qv[0]; v.y = qv[1]; e = qv[2]; e2 = qv[3];
         e4 = fq16(e4, s0);
     }
@@ -153,6 +162,81 @@ DEV void load_fwd_weights(FwdWeights &w, const float *__restrict__ wq, int j, in
     for (int r = 0; r < 4; ++r) w.bias2[r] = wq[G_B2 + 4 * g + r];
 }
 
+// Digit form of the forward weights (see the note on the QAT forward on the bf16 matrix cores below).  The prepared
+// weights are q * row scale with q an integer of at most 16 bits; the row scale is recovered as the row's largest
+// magnitude over 32767 (equal to the one that made it, up to one rounding, which cannot move rint(w / scale)).
+// A1h / A1l[t]: lane (g, j) holds the hi / lo digits of row 16 t + j at slots 8 g .. 8 g + 7 (slot = 6 * series + tap,
+// slots 30 and 31 zero); A2h / A2l: row j at k = (e < 4: neuron 4 g + e, else neuron 16 + 4 g + e - 4), which is what a
+// lane holds of h1.  sc1 / b1 [t][r], sc2 / b2 [r]: row scale times input scale, and bias, of the output neurons
+// 16 t + 4 g + r the lane holds of a result.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct FwdDigits {
+    u32x4 A1h[2], A1l[2], A2h, A2l;
+    f32x4 sc1[2], b1[2], sc2, b2;
+};
+DEV void digit_pair(float q0, float q1, unsigned &hi, unsigned &lo);
+template <bool FC2>
+DEV void load_fwd_digits(FwdDigits &w, const float *__restrict__ wq, float *scratch, int lane, int j, int g, float s_in,
+                         float s_h1) {
+    // row scales of W1 (32 rows) and W2 (16 rows): one row per lane, through the wave's LDS
+    {
+        float am = 0.f;
+        if (lane < 32) {
+            for (int k = 0; k < 30; ++k) am = fmaxf(am, fabsf(wq[G_W1 + lane * 30 + k]));
+        } else if (lane < 48) {
+            for (int k = 0; k < 32; ++k) am = fmaxf(am, fabsf(wq[G_W2 + (lane - 32) * 32 + k]));
+        }
+        scratch[lane] = scale_of(am);
+        __builtin_amdgcn_wave_barrier();
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 16 * t + j;
+        const float sw = scratch[n];
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ref = slot_ref(8 * g + e);
+            q[e] = ref >= 0 ? rintf(wq[G_W1 + n * 30 + ref] / sw) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned hi, lo;
+            digit_pair(q[2 * i], q[2 * i + 1], hi, lo);
+            w.A1h[t][i] = hi;
+            w.A1l[t][i] = lo;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            w.sc1[t][r] = scratch[16 * t + 4 * g + r] * s_in;
+            w.b1[t][r] = wq[G_B1 + 16 * t + 4 * g + r];
+        }
+    }
+    if (FC2) {
+        const float sw = scratch[32 + j];
+        float q[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int m = e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4);
+            q[e] = rintf(wq[G_W2 + j * 32 + m] / sw);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            unsigned hi, lo;
+            digit_pair(q[2 * i], q[2 * i + 1], hi, lo);
+            w.A2h[i] = hi;
+            w.A2l[i] = lo;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            w.sc2[r] = scratch[32 + 4 * g + r] * s_h1;
+            w.b2[r] = wq[G_B2 + 4 * g + r];
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 // tanh to fp32 rounding level: odd series below 0.1 (next term 62/2835 x^9 < 2e-11), above it
 // (1 - t) / (1 + t) with t = exp(-2|x|) (no cancellation left: 1 - t >= 0.18)
 DEV float tanh_f32(float x) {
@@ -171,10 +255,16 @@ DEV float tanh_f32(float x) {
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 // quad arithmetic as two packed instructions (the compiler leaves about half of such quads as four scalar
 // instructions; every VALU instruction costs the fp32 MFMAs issue time)
+// ASM = false wherever bf16 MFMAs may be in flight: an instruction inside an asm statement is invisible to the
+// compiler's hazard handling, and a VALU write to a register that a matrix instruction still executing reads or
+// writes needs wait states that nobody then inserts (seen as sporadic wrong values in the second tile of a pair; the
+// fp32 MFMA never showed it because nothing issues while one executes).
+template <bool ASM = true>
 DEV f32x4 mul4(f32x4 a, f32x4 b) {
 #ifdef NO_PK_ASM
     return a * b;
 #endif
+    if (!ASM) return a * b;
     f32x2 lo, hi;
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
     asm("v_pk_mul_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
@@ -182,6 +272,7 @@ DEV f32x4 mul4(f32x4 a, f32x4 b) {
 }
 // quantise-dequantise of a quad, the arithmetic of fq16(float, QS) element by element with its three
 // multiplies and two FMAs packed: 3 VALU instructions per element instead of 6
+template <bool ASM = true>
 DEV f32x4 fq16x4(f32x4 v, QS k) {
     const f32x2 inv = {k.inv, k.inv}, sc = {k.s, k.s};
     f32x4 out;
@@ -189,6 +280,16 @@ DEV f32x4 fq16x4(f32x4 v, QS k) {
     for (int i = 0; i < 2; ++i) {
         const f32x2 h = {v[2 * i], v[2 * i + 1]};
         f32x2 q0, t, q, r;
+        if (!ASM) {
+            q0 = h * inv;
+            q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, sc, h), inv, q0);
+            q[0] = rintf(q[0]);
+            q[1] = rintf(q[1]);
+            r = q * sc;
+            out[2 * i] = r[0];
+            out[2 * i + 1] = r[1];
+            continue;
+        }
         asm("v_pk_mul_f32 %0, %1, %2" : "=v"(q0) : "v"(h), "v"(inv));
         asm("v_pk_fma_f32 %0, %1, %2, %3 neg_lo:[1,0,0] neg_hi:[1,0,0]" : "=v"(t) : "v"(q0), "v"(sc), "v"(h));
         asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(q) : "v"(t), "v"(inv), "v"(q0));
@@ -202,20 +303,83 @@ DEV f32x4 fq16x4(f32x4 v, QS k) {
     }
     return out;
 }
+// ---- QAT forward on the bf16 matrix cores: exact 16-bit digits ---------------------------------------------------
+// A fake-quantised value is an integer of at most 16 bits times its tensor's (or row's) scale, and such an integer
+// is the sum of two bf16 numbers exactly: hi = its upper 8 significant bits (the upper 16 bits of the fp32 pattern),
+// lo = the rest (at most 8 bits).  So a layer of the QAT generator is an integer matrix product that the bf16 matrix
+// cores evaluate with four MFMAs of K = 32 per 16 x 16 tile (lo.lo, hi.lo, lo.hi, hi.hi into one fp32 accumulator,
+// small terms first: every product is exact, the accumulation rounds like any fp32 sum), and the two scales and
+// the bias enter once per output value: z = acc * (row scale * input scale) + b.  Against the fp32 MFMA form (GEN_QAT_DIGITS
+// = 0: 24 v_mfma_f32_16x16x4_f32 per tile at 32 cycles each, during which nothing else issues) this is 12
+// v_mfma_f32_16x16x32_bf16 at 16 cycles with VALU work issuing beside them; the quantiser's last multiply is
+// replaced by the digit split.  Same mathematical value as the reference's sum of products of dequantised numbers,
+// rounded in fewer places.
+#ifndef GEN_QAT_DIGITS
+#define GEN_QAT_DIGITS 1
+#endif
+#ifdef ABL_NO_MFMA
+DEV f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
+#else
+DEV f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+#endif
+// c + a x b for operands given as digit pairs
+DEV f32x4 mfma_digits(u32x4 ah, u32x4 al, u32x4 bh, u32x4 bl, f32x4 c) {
+    c = mfma_bf(al, bl, c);
+    c = mfma_bf(ah, bl, c);
+    c = mfma_bf(al, bh, c);
+    return mfma_bf(ah, bh, c);
+}
+// rint(v / s) of a quad: fq16x4 without its last multiply (the integers themselves); no asm, see mul4
+DEV f32x4 q16x4(f32x4 v, QS k) {
+    const f32x2 inv = {k.inv, k.inv}, sc = {k.s, k.s};
+    f32x4 out;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f32x2 h = {v[2 * i], v[2 * i + 1]};
+        const f32x2 q0 = h * inv;
+        const f32x2 q = __builtin_elementwise_fma(__builtin_elementwise_fma(-q0, sc, h), inv, q0);
+        out[2 * i] = rintf(q[0]);
+        out[2 * i + 1] = rintf(q[1]);
+    }
+    return out;
+}
+DEV float q16(float v, QS k) {
+    const float q0 = v * k.inv;
+    return rintf(__builtin_fmaf(__builtin_fmaf(-q0, k.s, v), k.inv, q0));
+}
+// two float integers -> their hi digits as a bf16 pair, their lo digits as a bf16 pair
+DEV void digit_pair(float q0, float q1, unsigned &hi, unsigned &lo) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, q0), u1 = __builtin_bit_cast(unsigned, q1);
+    hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+    const float l0 = q0 - __builtin_bit_cast(float, u0 & 0xffff0000u), l1 = q1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    lo = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l0), 0x07060302u);
+}
+// one float integer -> the word (hi digit << 16 | lo digit) a series holds per point
+DEV float digit_word(float q) {
+    const unsigned u = __builtin_bit_cast(unsigned, q);
+    const float l = q - __builtin_bit_cast(float, u & 0xffff0000u);
+    return __builtin_bit_cast(float, __builtin_amdgcn_perm(u, __builtin_bit_cast(unsigned, l), 0x07060302u));
+}
+
 // LeakyReLU of a quad without a comparison: max(z, slope z) for slope <= 1, min(z, slope z) above,
 // as the median of (z, slope z, +-inf); the product is the one the comparing form selects
+template <bool ASM = true>
 DEV f32x4 lrelu4(f32x4 z, float slope) {
-    const f32x4 p = mul4(z, f32x4{slope, slope, slope, slope});
+    const f32x4 p = mul4<ASM>(z, f32x4{slope, slope, slope, slope});
     const float sel = slope <= 1.f ? __builtin_inff() : -__builtin_inff();
     f32x4 h;
 #pragma unroll
     for (int r = 0; r < 4; ++r) h[r] = __builtin_amdgcn_fmed3f(z[r], p[r], sel);
     return h;
 }
+template <bool ASM = true>
 DEV f32x4 add4(f32x4 a, f32x4 b) {
 #ifdef NO_PK_ASM
     return a + b;
 #endif
+    if (!ASM) return a + b;
     f32x2 lo, hi;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(lo) : "v"(f32x2{a[0], a[1]}), "v"(f32x2{b[0], b[1]}));
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(hi) : "v"(f32x2{a[2], a[3]}), "v"(f32x2{b[2], b[3]}));
@@ -223,14 +387,32 @@ DEV f32x4 add4(f32x4 a, f32x4 b) {
 }
 // (the partial sums of the two outputs travel as a pair: packed multiplies and FMAs, half the VALU
 // instructions, which on this hardware take issue time away from the fp32 MFMAs one for one)
+// PACKED = false (kernels with bf16 MFMAs in flight): the partial sums on scalar FMAs.  With packed FMAs feeding the
+// row swaps, sixteen lanes of one output now and then came out wrong (a few tiles per 10^6, never the same ones)
+// once matrix instructions of other waves were executing beside them; the fp32-MFMA kernels, in which nothing issues
+// while a matrix instruction executes, never showed it.
+template <bool PACKED = true>
 DEV float fc3_pair(const f32x2 (&w3p)[4], float b3k, const f32x4 &hA, const f32x4 &hB) {
-    f32x2 pa = w3p[0] * f32x2{hA[0], hA[0]}, pb = w3p[0] * f32x2{hB[0], hB[0]};
+    float pa0, pa1, pb0, pb1;
+    if (PACKED) {
+        f32x2 pa = w3p[0] * f32x2{hA[0], hA[0]}, pb = w3p[0] * f32x2{hB[0], hB[0]};
 #pragma unroll
-    for (int r = 1; r < 4; ++r) {
-        pa = __builtin_elementwise_fma(w3p[r], f32x2{hA[r], hA[r]}, pa);
-        pb = __builtin_elementwise_fma(w3p[r], f32x2{hB[r], hB[r]}, pb);
+        for (int r = 1; r < 4; ++r) {
+            pa = __builtin_elementwise_fma(w3p[r], f32x2{hA[r], hA[r]}, pa);
+            pb = __builtin_elementwise_fma(w3p[r], f32x2{hB[r], hB[r]}, pb);
+        }
+        pa0 = pa[0]; pa1 = pa[1]; pb0 = pb[0]; pb1 = pb[1];
+    } else {
+        pa0 = w3p[0][0] * hA[0]; pa1 = w3p[0][1] * hA[0]; pb0 = w3p[0][0] * hB[0]; pb1 = w3p[0][1] * hB[0];
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            pa0 = __builtin_fmaf(w3p[r][0], hA[r], pa0);
+            pa1 = __builtin_fmaf(w3p[r][1], hA[r], pa1);
+            pb0 = __builtin_fmaf(w3p[r][0], hB[r], pb0);
+            pb1 = __builtin_fmaf(w3p[r][1], hB[r], pb1);
+        }
+        asm volatile("" : "+v"(pa0), "+v"(pa1), "+v"(pb0), "+v"(pb1));      // (keeps the compiler from packing them again)
     }
-    const float pa0 = pa[0], pa1 = pa[1], pb0 = pb[0], pb1 = pb[1];
     // halves: lanes 0..31 collect tile A (rows g and g + 2), lanes 32..63 tile B
     const auto h0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa0), __builtin_bit_cast(unsigned, pb0), false, false);
     const auto h1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, pa1), __builtin_bit_cast(unsigned, pb1), false, false);
@@ -265,8 +447,12 @@ struct PaArgs {
 // packed FMAs.  3 ("carry"): a wave walks whole rows (unit == chunks per row), chunks do not overlap: the last M - 1
 // generator outputs of a chunk stay in LDS for the next chunk of the row, whose lanes then evaluate the PA outputs
 // t0 - 4 .. t0 + 59.  No generator output is computed twice; the host picks it when the rows fill the waves evenly.
+// (the digit form with the PA twin needs a few registers more than four waves per SIMD leave: three there)
+#ifndef FWD_WAVES_DIGITS_PA
+#define FWD_WAVES_DIGITS_PA 3
+#endif
 template <bool QAT, int DEPTH, int PAV>
-__global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
+__global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? FWD_WAVES_DIGITS_PA : FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
                                                              int64_t cpr, int64_t n_chunks,
                                                              const float *__restrict__ wq, float slope,
                                                              float *__restrict__ absmax, float2 *__restrict__ out,
@@ -307,18 +493,9 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
     float2 *const ybuf = reinterpret_cast<float2 *>(ser + TG_W);
     constexpr int YB0 = CARRY ? 4 : 0;
     static_assert(TG_W + 2 * (CHUNK + 4) <= SER_WORDS, "room for the carried outputs");
+    constexpr bool DIG = QAT && GEN_QAT_DIGITS;
     FwdWeights w;
-    load_fwd_weights(w, wq, j, g);
-    int boff[8];
-#pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        int slot = 4 * s + g;
-        boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
-    }
-    f32x2 w3p[4];     // (W3[0][4g + r], W3[1][4g + r]): FC3 runs on the VALU
-#pragma unroll
-    for (int r = 0; r < 4; ++r) w3p[r] = f32x2{wq[G_W3 + 4 * g + r], wq[G_W3 + 16 + 4 * g + r]};
-    const float b3k = wq[G_B3 + (g & 1)];
+    FwdDigits wd;
     QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
     if (QAT) {
         s0 = qs_of(absmax[0]);
@@ -326,16 +503,44 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         if (DEPTH >= 3) s2 = qs_of(absmax[2]);
         if (PA) s3 = qs_of(absmax[3]);
     }
+    if constexpr (DIG) load_fwd_digits<(DEPTH >= 2)>(wd, wq, ser, lane, j, g, s0.s, s1.s);
+    else load_fwd_weights(w, wq, j, g);
+    int boff[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        // fp32 form: k-step s takes slot 4 s + g; digit form: the lane group's eight consecutive slots 8 g + s
+        int slot = DIG ? 8 * g + s : 4 * s + g;
+        boff[s] = 4 * ((DIG && slot >= 30 ? ZERO_W : slot_word(slot)) + (slot < 30 ? j : 0));
+    }
+    f32x2 w3p[4];     // (W3[0][4g + r], W3[1][4g + r]): FC3 runs on the VALU
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w3p[r] = f32x2{wq[G_W3 + 4 * g + r], wq[G_W3 + 16 + 4 * g + r]};
+    const float b3k = wq[G_B3 + (g & 1)];
     float amax = 0.f;
     const char *const ser_b = reinterpret_cast<const char *>(ser);
     const bool odd = (g & 1) != 0;
 
     struct Tile {
         f32x4 a0, a1, ha, hb, c0, c1, h2;
+        u32x4 xh, xl;          // digit form: the tile's h1 as FC2 operands
     };
     auto S1 = [&](Tile &t, int c) {
-        t.a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
+        t.a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30 (fp32 form) or with the scale (digit form)
         t.a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (DIG) {
+            unsigned d[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) d[e] = *reinterpret_cast<const unsigned *>(ser_b + boff[e] + 64 * c);
+            u32x4 xh, xl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                xh[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x07060302u);
+                xl[i] = __builtin_amdgcn_perm(d[2 * i + 1], d[2 * i], 0x05040100u);
+            }
+            t.a0 = mfma_digits(wd.A1h[0], wd.A1l[0], xh, xl, t.a0);
+            t.a1 = mfma_digits(wd.A1h[1], wd.A1l[1], xh, xl, t.a1);
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             float b = *reinterpret_cast<const float *>(ser_b + boff[s] + 64 * c);
@@ -365,11 +570,26 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         }
     };
     auto V1 = [&](Tile &t, bool valid, bool full) {
+        if constexpr (DIG) {            // the integer sums become pre-activations: scales and bias, once per value
+            t.a0 = __builtin_elementwise_fma(t.a0, wd.sc1[0], wd.b1[0]);
+            t.a1 = __builtin_elementwise_fma(t.a1, wd.sc1[1], wd.b1[1]);
+        }
         if (QAT && DEPTH == 1 && slope >= 0.f) {
             extremes(t.a0, t.a1, valid, full);
             return;
         }
-        const f32x4 x0 = lrelu4(t.a0, slope), x1 = lrelu4(t.a1, slope);
+        const f32x4 x0 = lrelu4<!DIG>(t.a0, slope), x1 = lrelu4<!DIG>(t.a1, slope);
+        if constexpr (DIG && DEPTH >= 2) {
+            const f32x4 q0 = q16x4(x0, s1), q1 = q16x4(x1, s1);
+            unsigned dh[4], dl[4];
+            digit_pair(q0[0], q0[1], dh[0], dl[0]);
+            digit_pair(q0[2], q0[3], dh[1], dl[1]);
+            digit_pair(q1[0], q1[1], dh[2], dl[2]);
+            digit_pair(q1[2], q1[3], dh[3], dl[3]);
+            t.xh = u32x4{dh[0], dh[1], dh[2], dh[3]};
+            t.xl = u32x4{dl[0], dl[1], dl[2], dl[3]};
+            return;
+        }
         t.ha = (QAT && DEPTH >= 2) ? fq16x4(x0, s1) : x0;
         t.hb = (QAT && DEPTH >= 2) ? fq16x4(x1, s1) : x1;
         if (QAT && DEPTH == 1) {
@@ -378,6 +598,10 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         }
     };
     auto S2 = [&](Tile &t) {
+        if constexpr (DIG) {
+            t.c0 = mfma_digits(wd.A2h, wd.A2l, t.xh, t.xl, f32x4{0.f, 0.f, 0.f, 0.f});
+            return;
+        }
         t.c0 = w.bias2;
         t.c1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -387,13 +611,15 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
         }
     };
     auto V2 = [&](Tile &t, bool valid, bool full) {
+        f32x4 z2;
+        if constexpr (DIG) z2 = __builtin_elementwise_fma(t.c0, wd.sc2, wd.b2);
+        else z2 = add4<!DIG>(t.c0, t.c1);
         if (QAT && DEPTH == 2 && slope >= 0.f) {
-            const f32x4 z = add4(t.c0, t.c1);
-            extremes(z, z, valid, full);
+            extremes(z2, z2, valid, full);
             return;
         }
-        const f32x4 x = lrelu4(add4(t.c0, t.c1), slope);
-        t.h2 = (QAT && DEPTH >= 3) ? fq16x4(x, s2) : x;
+        const f32x4 x = lrelu4<!DIG>(z2, slope);
+        t.h2 = (QAT && DEPTH >= 3) ? fq16x4<!DIG>(x, s2) : x;
         if (QAT && DEPTH == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) amax = fmaxf(amax, valid ? fabsf(x[r]) : 0.f);
@@ -426,14 +652,14 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
     if (chunk < n_chunks32) fetch(row, pos, true);
     while (chunk < n_chunks32) {
         if (fresh) {
-            if (lane < H) commit_point<QAT>(ser, pre_h, lane, s0);
+            if (lane < H) commit_point<QAT, DIG>(ser, pre_h, lane, s0);
         } else {
             for (int c = lane; c < 5 * H; c += 64) {
                 const int type = c / H, w0 = SER_BASE0 + SER_STRIDE * type + (c - type * H);
                 ser[w0] = ser[w0 + chunk_step];
             }
         }
-        if (lane < chunk_step) commit_point<QAT>(ser, pre, H + lane, s0);
+        if (lane < chunk_step) commit_point<QAT, DIG>(ser, pre, H + lane, s0);
         const int64_t t0_cur = (int64_t)pos * chunk_step, row_cur = row;
         // next chunk of this wave
         if (++k_in_unit < unit) {
@@ -477,7 +703,7 @@ __global__ __launch_bounds__(WAVES * 64, FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma
                 if (DEPTH >= 3) {
                     V2(B, vB, fB);
                     // lane (g, j): output g & 1 of sample j of tile g >> 1
-                    float y = tanh_f32(fc3_pair(w3p, b3k, A.h2, B.h2));
+                    float y = tanh_f32(fc3_pair<!DIG>(w3p, b3k, A.h2, B.h2));
                     const int tl = 32 * p + 16 * (g >> 1) + j;          // output index inside the chunk
                     const bool in_row = tl < rem;                        // rem: outputs left in the row from t0_cur (scalar)
                     if (QAT && !PA) amax = fmaxf(amax, in_row ? fabsf(y) : 0.f);

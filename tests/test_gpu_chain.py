@@ -214,3 +214,40 @@ def test_gen_pa_forward_qat_entry_point(shape):
     d_ref = og.gen_forward(x.cpu(), params, qat=True)
     y_ref = opa.volterra_forward(d_ref, cre.cpu(), cim.cpu())
     close(y, y_ref.numpy(), rtol=1e-5, atol=1e-4 * scale)                       # measured: 3.0e-5 of the peak
+
+
+def test_qat_forward_repeats_bit_for_bit_under_load():
+    """The QAT forward kernels (bf16 matrix cores, VALU work issuing beside the matrix instructions of other waves) have
+    no atomics and no order-dependent sums: at a size that fills every SIMD, repeated launches must give identical bits,
+    and the generator output of the fused chain must equal the four-pass forward (guards instruction hazards that only
+    show as a few wrong tiles per million under contention)."""
+    from dpd_amd import _lib as L
+    from dpd_amd.data import ofdm_rows
+    from dpd_amd.models import PADigitalTwin, TDNNGeneratorQAT
+    B, S = 4096, 1029
+    iq = ofdm_rows(B, S, seed=77, device=DEV)
+    torch.manual_seed(0)
+    gen = TDNNGeneratorQAT().to(DEV).eval()
+    pa = PADigitalTwin().to(DEV)
+    ps = [gen.fc1.weight, gen.fc1.bias, gen.fc2.weight, gen.fc2.bias, gen.fc3.weight, gen.fc3.bias]
+    wq = torch.empty(L.GEN_NPARAM, device=DEV)
+    absmax = torch.zeros(L.GEN_NSCALE, device=DEV)
+    st = L.stream()
+    L.call("dpd_gen_prepare_weights", *(L.fptr(p.detach()) for p in ps), 1, L.fptr(wq), L.fptr(absmax), st)
+    out = torch.empty(B, S - 5, 2, device=DEV)
+    for stage in range(4):
+        L.call("dpd_gen_absmax_pass", stage, L.fptr(iq), B, S, 0, L.fptr(wq), 0.2, L.fptr(absmax), L.fptr(out), 0, st)
+    L.call("dpd_gen_forward", L.fptr(iq), B, S, 0, L.fptr(wq), 0.2, 1, L.fptr(absmax), L.fptr(out), 2, st)
+    ref = out.clone()
+    cre, cim = pa.pa_model.coeffs_real.contiguous(), pa.pa_model.coeffs_imag.contiguous()
+    yb = torch.empty(B, S - 9, 2, device=DEV)
+    out2 = torch.empty(B, S - 5, 2, device=DEV)
+    first = None
+    for _ in range(12):
+        L.call("dpd_gen_forward", L.fptr(iq), B, S, 0, L.fptr(wq), 0.2, 1, L.fptr(absmax), L.fptr(out), 2, st)
+        L.call("dpd_gen_pa_forward", L.fptr(iq), B, S, L.fptr(wq), 0.2, 1, L.fptr(absmax), L.fptr(cre), L.fptr(cim), 4, 5,
+               L.fptr(out2), L.fptr(yb), st)
+        assert torch.equal(out, ref) and torch.equal(out2, ref)
+        if first is None:
+            first = yb.clone()
+        assert torch.equal(yb, first)
