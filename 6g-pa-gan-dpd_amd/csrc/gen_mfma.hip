@@ -1,5 +1,7 @@
 // Generator kernels, MFMA family (gfx950): tap assembly + 30->32->16->2 forward (+ backward) fused
-// per 16-sample tile on v_mfma_f32_16x16x4_f32.  Reference semantics as in gen_valu.hip.
+// per 16-sample tile on v_mfma_f32_16x16x4_f32 (float generator, and every backward product); the forward layers of
+// the QAT generator run as exact digit products on v_mfma_f32_16x16x32_bf16 (see mfma_digits).  Reference semantics
+// as in gen_valu.hip.
 //
 // Geometry.  A wave owns a chunk of 64 consecutive output samples of one IQ row (4 tiles of 16).
 // Lane l = (g = l >> 4, j = l & 15).  Every product is computed transposed, D = W * X^T, so that
@@ -50,6 +52,10 @@ constexpr int H1_W = GZ_W + 16 * P32;
 constexpr int BWD_WORDS = SER_WORDS + 2 * TILE_W;   // 3736 words per wave
 static_assert(WAVES * BWD_WORDS >= WAVES * G_SLAB, "the gradient rows are combined in the staging LDS");
 static_assert((size_t)WAVES * BWD_WORDS * sizeof(float) <= 65536, "static LDS of the backward kernel: 58.4 KiB, two workgroups per CU");
+// backward in the digit form: the five series a second time, as digit words (FC1 operands), between the series and the
+// tile buffers; the series themselves then hold the quantised integers as floats (the x operand of dW1)
+constexpr int DSER_WORDS = 356;
+static_assert((size_t)WAVES * (BWD_WORDS + DSER_WORDS) * sizeof(float) <= 65536, "63.9 KiB, two workgroups per CU");
 
 #ifdef ABL_NO_MFMA      // experiment (timing only, results are wrong): every matrix instruction dropped, its dependencies kept
 DEV f32x4 mfma4(float a, float b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
@@ -115,6 +121,28 @@ DEV void commit_series(float *ser, const ChunkIQ &c, int lane, QS s0) {
         p[2 * SER_STRIDE] = e;
         p[3 * SER_STRIDE] = e2;
         p[4 * SER_STRIDE] = e4;
+    }
+}
+// Digit form of the backward: the quantised integers as floats in the series (dW1 contracts them with gz1 and is scaled
+// by the input scale once, at the end of the kernel), their digit words in the second set of series at dser.
+DEV void commit_series_digits(float *ser, float *dser, const ChunkIQ &c, int lane, QS s0) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        int tau = lane + 64 * rep;
+        if (rep == 1 && lane >= 5) break;
+        const float2 v = c.p[rep];
+        const float e = sqrtf(v.x * v.x + v.y * v.y);
+        const float e2 = e * e;
+        const float e4 = e2 * e2;
+        const f32x4 qv = q16x4(f32x4{v.x, v.y, e, e2}, s0);
+        const float q4 = q16(e4, s0);
+        float *p = ser + SER_BASE0 + tau, *d = dser + tau;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const float q = k < 4 ? qv[k] : q4;
+            p[k * SER_STRIDE] = q;
+            d[k * SER_STRIDE] = digit_word(q);
+        }
     }
 }
 // One time point: derive its five series values and park them at position tau of the chunk's series.
@@ -313,7 +341,9 @@ DEV f32x4 fq16x4(f32x4 v, QS k) {
 // = 0: 24 v_mfma_f32_16x16x4_f32 per tile at 32 cycles each, during which nothing else issues) this is 12
 // v_mfma_f32_16x16x32_bf16 at 16 cycles with VALU work issuing beside them; the quantiser's last multiply is
 // replaced by the digit split.  Same mathematical value as the reference's sum of products of dequantised numbers,
-// rounded in fewer places.
+// rounded in fewer places.  The fused training kernels use the same form for FC1 and FC2 of their forward half (identical
+// operand order, so the pre-activations equal those of the abs-max passes bit for bit); their weight gradients contract
+// the integers (series and h1, kept as floats beside the digits) and take the tensor scale once at the end of the kernel.
 #ifndef GEN_QAT_DIGITS
 #define GEN_QAT_DIGITS 1
 #endif
@@ -873,10 +903,17 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
                                                              const float2 *__restrict__ target, float mse_scale,
                                                              float *__restrict__ slab, unsigned *__restrict__ queue,
                                                              PaBwdArgs pa) {
-    __shared__ __attribute__((aligned(16))) float lds[WAVES * BWD_WORDS];   // static: addresses fold into the instructions
+    // DIG: FC1 and FC2 of the forward half as digit products on the bf16 matrix cores (see the note at mfma_digits); the
+    // backward half keeps the fp32 MFMA.  No asm-wrapped VALU instructions and no packed FMAs in front of row swaps then.
+    constexpr bool DIG = QAT && GEN_QAT_DIGITS;
+    constexpr int WAVE_WORDS = BWD_WORDS + (DIG ? DSER_WORDS : 0);
+    constexpr int DSER_W = SER_WORDS;                              // digit series (DIG only)
+    constexpr int GZ_W = SER_WORDS + (DIG ? DSER_WORDS : 0);       // + TILE_W * buffer (these two shadow the namespace-scope ones)
+    constexpr int H1_W = GZ_W + 16 * P32;
+    __shared__ __attribute__((aligned(16))) float lds[WAVES * WAVE_WORDS];   // static: addresses fold into the instructions
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: chunk, row and position arithmetic run on the scalar unit
-    float *ser = lds + wave * BWD_WORDS;
+    float *ser = lds + wave * WAVE_WORDS;
     ser[ZERO_W + lane] = 0.f;
     ser[ONE_W + lane] = 1.f;
     if (PA && lane < 48) {   // coefficient block of this wave: [tap][re k0..3 | im k0..3], orders >= K and tap 5 are zero
@@ -884,8 +921,17 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         const float *src = (lane & 4) ? pa.cim : pa.cre;
         ser[PAC_W + lane] = (m < PA_M && k < pa.K) ? src[k * PA_M + m] : 0.f;
     }
+    QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
+    if (QAT) {
+        s0 = qs_of(absmax[0]);
+        s1 = qs_of(absmax[1]);
+        s2 = qs_of(absmax[2]);
+        s3 = qs_of(absmax[3]);
+    }
     FwdWeights w;
-    load_fwd_weights(w, wq, j, g);
+    FwdDigits wd;
+    if constexpr (DIG) load_fwd_digits<true>(wd, wq, ser + GZ_W, lane, j, g, s0.s, s1.s);
+    else load_fwd_weights(w, wq, j, g);
     float A2T[2][4];  // W2[4g + r][16t + i]
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -903,8 +949,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     int boff[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        int slot = 4 * s + g;
-        boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
+        // fp32 form: k-step s takes slot 4 s + g; digit form: the lane group's eight consecutive slots 8 g + s, digit series
+        int slot = DIG ? 8 * g + s : 4 * s + g;
+        if (DIG) boff[s] = 4 * (slot >= 30 ? ZERO_W : DSER_W + slot_word(slot) - SER_BASE0 + j);
+        else boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
     // dW1 A operand: lane (i = j, g) reads slot 16u + i of sample 4q + g
     int aoff[2];
@@ -922,14 +970,6 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         rd32[q] = 4 * (s * P32 + (j ^ swz(s)));
     }
     char *const ser_b = reinterpret_cast<char *>(ser);
-
-    QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
-    if (QAT) {
-        s0 = qs_of(absmax[0]);
-        s1 = qs_of(absmax[1]);
-        s2 = qs_of(absmax[2]);
-        s3 = qs_of(absmax[3]);
-    }
     f32x4 dW1[2][2], dW2[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
@@ -952,6 +992,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     //   S1A | S1B+V1A | S2A+V1B | S2B+V2A | V2B+V3(A,B)+V4A | S5A+V4B | S5B+V5A | S6A+V5B | S6B
     struct Tile {
         f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, gz2, e0, e1;
+        u32x4 xh, xl;          // digit form: the tile's h1 as FC2 operands (ha, hb, c1 unused then)
     };
     // FC1 operands are fetched from LDS one stage before the MFMAs that use them.  A tile is named by the
     // byte offset of its first sample inside the chunk's series (64 * tile, or 4 * (28 * pair + 16 * half) in
@@ -964,8 +1005,20 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         for (int s = 0; s < 8; ++s) b.v[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + toff);
     };
     auto S1 = [&](f32x4 &a0, f32x4 &a1, const Fc1Operand &b) {
-        a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30
+        a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30 (fp32 form) or with the scales (digit form)
         a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (DIG) {
+            u32x4 xh, xl;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const unsigned d0 = __builtin_bit_cast(unsigned, b.v[2 * i]), d1 = __builtin_bit_cast(unsigned, b.v[2 * i + 1]);
+                xh[i] = __builtin_amdgcn_perm(d1, d0, 0x07060302u);
+                xl[i] = __builtin_amdgcn_perm(d1, d0, 0x05040100u);
+            }
+            a0 = mfma_digits(wd.A1h[0], wd.A1l[0], xh, xl, a0);
+            a1 = mfma_digits(wd.A1h[1], wd.A1l[1], xh, xl, a1);
+            return;
+        }
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             a0 = mfma4(w.A1[0][s], b.v[s], a0);
@@ -973,20 +1026,41 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         }
     };
     auto V1 = [&](Tile &t, int buf) {
+        if constexpr (DIG) {            // the integer sums become pre-activations: scales and bias, once per value
+            t.a0 = __builtin_elementwise_fma(t.a0, wd.sc1[0], wd.b1[0]);
+            t.a1 = __builtin_elementwise_fma(t.a1, wd.sc1[1], wd.b1[1]);
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             t.m1a[r] = t.a0[r] > 0.f ? 1.f : slope;
             t.m1b[r] = t.a1[r] > 0.f ? 1.f : slope;
         }
-        t.a0 = mul4(t.a0, t.m1a);
-        t.a1 = mul4(t.a1, t.m1b);
-        t.ha = QAT ? fq16x4(t.a0, s1) : t.a0;
-        t.hb = QAT ? fq16x4(t.a1, s1) : t.a1;
+        t.a0 = mul4<!DIG>(t.a0, t.m1a);
+        t.a1 = mul4<!DIG>(t.a1, t.m1b);
+        if constexpr (DIG) {
+            // h1 as integers: digits for FC2, the integers themselves (as floats) for dW2, which is scaled once at the end
+            t.ha = q16x4(t.a0, s1);
+            t.hb = q16x4(t.a1, s1);
+            unsigned dh[4], dl[4];
+            digit_pair(t.ha[0], t.ha[1], dh[0], dl[0]);
+            digit_pair(t.ha[2], t.ha[3], dh[1], dl[1]);
+            digit_pair(t.hb[0], t.hb[1], dh[2], dl[2]);
+            digit_pair(t.hb[2], t.hb[3], dh[3], dl[3]);
+            t.xh = u32x4{dh[0], dh[1], dh[2], dh[3]};
+            t.xl = u32x4{dl[0], dl[1], dl[2], dl[3]};
+        } else {
+            t.ha = QAT ? fq16x4(t.a0, s1) : t.a0;
+            t.hb = QAT ? fq16x4(t.a1, s1) : t.a1;
+        }
         char *h1_b = ser_b + 4 * (H1_W + TILE_W * buf);
         *reinterpret_cast<f32x4 *>(h1_b + wr32) = t.ha;
         *reinterpret_cast<f32x4 *>(h1_b + wr32 + 64) = t.hb;
     };
     auto S2 = [&](Tile &t) {
+        if constexpr (DIG) {
+            t.c0 = mfma_digits(wd.A2h, wd.A2l, t.xh, t.xl, f32x4{0.f, 0.f, 0.f, 0.f});
+            return;
+        }
         t.c0 = w.bias2;
         t.c1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -996,11 +1070,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         }
     };
     auto V2 = [&](Tile &t) {
-        t.c0 = add4(t.c0, t.c1);
+        if constexpr (DIG) t.c0 = __builtin_elementwise_fma(t.c0, wd.sc2, wd.b2);
+        else t.c0 = add4(t.c0, t.c1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) t.m2[r] = t.c0[r] > 0.f ? 1.f : slope;
-        t.c0 = mul4(t.c0, t.m2);
-        t.h2 = QAT ? fq16x4(t.c0, s2) : t.c0;
+        t.c0 = mul4<!DIG>(t.c0, t.m2);
+        t.h2 = QAT ? fq16x4<!DIG>(t.c0, s2) : t.c0;
     };
     // Output stage of a tile pair: 32 samples x 2 outputs = one (sample, output) per lane.  Lane (g, j)
     // takes output g & 1 of sample j of tile g >> 1, so tanh, loss and gz3 are evaluated once each; gz3
@@ -1087,7 +1162,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         return __builtin_fmaf(2.f * (c ? ui : ur), b, c ? ai : ar);
     };
     auto V3P = [&](Tile &A, Tile &B, int p, int64_t t0_cur) {
-        const float y = tanh_f32(fc3_pair(w3p, b3k, A.h2, B.h2));
+        const float y = tanh_f32(fc3_pair<!DIG>(w3p, b3k, A.h2, B.h2));
         float gup;
         if constexpr (PA) {
             gup = pa_stage(y, p, t0_cur);
@@ -1122,10 +1197,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         dW3[1] = __builtin_elementwise_fma(a1v, A.h2, dW3[1]);
         dW3[0] = __builtin_elementwise_fma(b0v, B.h2, dW3[0]);
         dW3[1] = __builtin_elementwise_fma(b1v, B.h2, dW3[1]);
-        A.gz2 = mul4(__builtin_elementwise_fma(w3r[1], a1v, mul4(w3r[0], a0v)), A.m2);
-        B.gz2 = mul4(__builtin_elementwise_fma(w3r[1], b1v, mul4(w3r[0], b0v)), B.m2);
-        db2 = add4(db2, A.gz2);
-        db2 = add4(db2, B.gz2);
+        A.gz2 = mul4<!DIG>(__builtin_elementwise_fma(w3r[1], a1v, mul4<!DIG>(w3r[0], a0v)), A.m2);
+        B.gz2 = mul4<!DIG>(__builtin_elementwise_fma(w3r[1], b1v, mul4<!DIG>(w3r[0], b0v)), B.m2);
+        db2 = add4<!DIG>(db2, A.gz2);
+        db2 = add4<!DIG>(db2, B.gz2);
     };
     auto V4 = [&](Tile &t, int buf) {
         *reinterpret_cast<f32x4 *>(ser_b + 4 * (GZ_W + TILE_W * buf) + wr32 + 128) = t.gz2;
@@ -1140,8 +1215,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         }
     };
     auto V5 = [&](Tile &t, int buf) {
-        t.e0 = mul4(t.e0, t.m1a);
-        t.e1 = mul4(t.e1, t.m1b);
+        t.e0 = mul4<!DIG>(t.e0, t.m1a);
+        t.e1 = mul4<!DIG>(t.e1, t.m1b);
         char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
         *reinterpret_cast<f32x4 *>(gz_b + wr32) = t.e0;
         *reinterpret_cast<f32x4 *>(gz_b + wr32 + 64) = t.e1;
@@ -1249,7 +1324,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         { unsigned long long now = __builtin_readcyclecounter(); tacc[17] += now - tlast; tlast = now; }
 #endif
-        commit_series<QAT>(ser, pre, lane, s0);
+        if constexpr (DIG) commit_series_digits(ser, ser + DSER_W, pre, lane, s0);
+        else commit_series<QAT>(ser, pre, lane, s0);
         tg_lds[lane] = pre_tg;
 #ifdef ABL_TIMING
         { __builtin_amdgcn_sched_barrier(0); unsigned long long now = __builtin_readcyclecounter(); tacc[16] += now - tlast; tlast = now; __builtin_amdgcn_sched_barrier(0); }
@@ -1339,13 +1415,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int slot = 16 * u + 4 * g + r, ref = slot_ref(slot);
-                if (ref >= 0) rowp[G_W1 + (16 * t + j) * 30 + ref] = dW1[u][t][r];
+                if (ref >= 0) rowp[G_W1 + (16 * t + j) * 30 + ref] = DIG ? dW1[u][t][r] * s0.s : dW1[u][t][r];
                 else if (slot == 30) rowp[G_B1 + 16 * t + j] = dW1[u][t][r];   // sum over samples of 1 * gz1
             }
 #pragma unroll
     for (int u = 0; u < 2; ++u)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rowp[G_W2 + j * 32 + 16 * u + 4 * g + r] = dW2[u][r];
+        for (int r = 0; r < 4; ++r) rowp[G_W2 + j * 32 + 16 * u + 4 * g + r] = DIG ? dW2[u][r] * s1.s : dW2[u][r];
     // per-lane accumulators: sum over the 16 sample lanes of each lane group
 #pragma unroll
     for (int off = 1; off < 16; off <<= 1) {

@@ -251,3 +251,36 @@ def test_qat_forward_repeats_bit_for_bit_under_load():
         if first is None:
             first = yb.clone()
         assert torch.equal(yb, first)
+
+
+def test_qat_backward_repeats_bit_for_bit_under_load():
+    """The fused QAT training kernels run their forward half on the bf16 matrix cores beside the VALU stages of other
+    waves.  In deterministic mode (chunks in a fixed order, fixed summation order) repeated launches of the Stage-1 step
+    kernel and of the chain step kernel must give identical gradients and losses, at a size that fills every SIMD."""
+    from dpd_amd import _lib as L
+    from dpd_amd.data import ofdm_rows
+    from dpd_amd.models import PADigitalTwin, TDNNGeneratorQAT
+    from dpd_amd.training import ChainStep, Stage1Step
+    B, S = 4096, 1029
+    iq = ofdm_rows(B, S, seed=78, device=DEV)
+    tgt = iq[:, 5:, :].contiguous()
+    torch.manual_seed(0)
+    gen = TDNNGeneratorQAT().to(DEV).train()
+    gen.qat_enabled = True
+    pa = PADigitalTwin().to(DEV)
+    L.call("dpd_set_option", b"gen_deterministic", 1)
+    try:
+        for make, target in ((lambda: Stage1Step(gen, optimizer=torch.optim.SGD(gen.parameters(), lr=0.0)), tgt),
+                             (lambda: ChainStep(gen, pa, optimizer=torch.optim.SGD(gen.parameters(), lr=0.0)),
+                              (tgt[:, 4:, :] * 31.0).contiguous())):
+            step = make()
+            first = None
+            for _ in range(12):
+                step(iq, target)
+                g = step.grads[:L.GEN_NPARAM + 1].clone()
+                assert bool(torch.isfinite(g).all())
+                if first is None:
+                    first = g
+                assert torch.equal(g, first)
+    finally:
+        L.call("dpd_set_option", b"gen_deterministic", 0)
