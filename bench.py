@@ -50,8 +50,17 @@ PA_BWD_FLOP = 400
 # gradients of the two inner layers (30) as three-way-split bf16 operands on v_mfma_f32_16x16x32_bf16 (16 cycles)
 CRITIC_BWD_BF16_MFMA = 90
 # k_q88_mfma, per chunk of 64 samples and wave, counted in the loop body of the compiled kernel (scratch/isa_hist.py)
-Q88_VALU_PER_CHUNK = 634
+Q88_VALU_PER_CHUNK = 604
 Q88_MFMA_PER_CHUNK = 40
+# QAT generator kernels in the digit form (fake-quantised values as two exact bf16 digits), per chunk of 64 samples and
+# wave, counted in the loop bodies of the compiled kernels (scratch/isa_hist.py): vector-ALU instructions, bf16 MFMAs
+# (v_mfma_f32_16x16x32_bf16, 16 cycles on the matrix pipe, 4 on the issue port) and fp32 MFMAs (v_mfma_f32_16x16x4_f32,
+# 32 cycles during which the SIMD issues nothing else)
+GEN_QAT_FWD_P4 = {"valu": 579, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,3,0>: last abs-max pass
+GEN_QAT_FWD_PA = {"valu": 625, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,4,3>: fused chain forward
+GEN_QAT_BWD = {"valu": 680, "bf16": 48, "fp32": 128}        # k_gen_bwd_mfma<true,true,false>: Stage-1 step
+GEN_QAT_BWD_PA = {"valu": 996, "bf16": 48, "fp32": 128}     # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
+GEN_FLOAT_BWD = {"valu": 348, "bf16": 0, "fp32": 224}       # k_gen_bwd_mfma<false,true,false>
 CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + CRITIC_BWD_BF16_MFMA * 16
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
@@ -185,7 +194,7 @@ def pmc_bytes(key):
     """HBM bytes per launch of a kernel from the rocprofv3 counter passes recorded under profiles/
     (TCC_EA read and write requests converted to bytes as the microarchitecture guide prescribes).  The counters cannot
     be read from inside this process; the figures apply to the default shape only."""
-    for name in ("r2_pmc_stage2.json", "r2_pmc_extras.json", "r1_stage1_pmc.json"):
+    for name in ("r3_pmc_stage2.json", "r3_pmc_extras.json", "r2_pmc_stage2.json", "r2_pmc_extras.json", "r1_stage1_pmc.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -197,6 +206,16 @@ def pmc_bytes(key):
         except (OSError, KeyError, ValueError, TypeError):
             continue
     return None
+
+
+def simd_time_fracs(counts, chunks, k):
+    """Utilisation figures of a kernel from its per-chunk instruction counts: `matrix` = cycles its MFMAs occupy the matrix
+    pipe (fp32 16x16x4: 32, bf16 16x16x32: 16) over the measured cycles per SIMD; `issue` = cycles its vector instructions
+    hold the SIMD's issue port (VALU 4, bf16 MFMA 4, fp32 MFMA all of its 32) over the same."""
+    cyc = k * CLOCK_HZ / (chunks / N_SIMD)
+    matrix = (counts["fp32"] * 32 + counts["bf16"] * 16) / cyc
+    issue = (counts["valu"] * 4 + counts["bf16"] * 4 + counts["fp32"] * 32) / cyc
+    return matrix, issue, cyc
 
 
 def default_shape(ctx):
@@ -230,9 +249,21 @@ def run_stage1(ctx, args, qat, steps, warmup):
     k = kt.avg_seconds()
     n = ctx.rows * (ctx.seq - 5)
     flop = 2.0 * (GEN_FWD_MAC + GEN_BWD_MAC) * n
-    roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma: tap assembly + forward + MSE + backward, fp32 MFMA (+ slab reduce)",
-            "achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS,
+    matrix, issue, cyc = simd_time_fracs(GEN_QAT_BWD if qat else GEN_FLOAT_BWD, n / 64.0, k)
+    roof = {"bound": "mfma",
+            "kernel": ("k_gen_bwd_mfma<true,true,false>: tap assembly + forward (FC1, FC2 as exact digit products on the bf16 MFMA) + MSE + "
+                       "backward (fp32 MFMA) (+ slab reduce)" if qat else
+                       "k_gen_bwd_mfma<false,true,false>: tap assembly + forward + MSE + backward, fp32 MFMA (+ slab reduce)"),
+            # utilisation of the matrix pipes: cycles the kernel's MFMAs occupy them over the measured kernel cycles; `achieved`
+            # = frac x the fp32 MFMA peak (the pipe that carries the bulk of those cycles)
+            "achieved": matrix * FP32_PEAK_TFLOPS, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": matrix,
+            "frac_definition": "matrix-pipe utilisation: MFMA cycles of one launch (fp32 16x16x4 at 32 cycles, bf16 16x16x32 at 16, "
+                               "counted in the kernel's assembly) / measured kernel cycles per SIMD",
+            "issue_frac": issue, "cycles_per_64_samples": cyc,
+            # algorithmic fp32 flops (2 x (1,504 + 2,048) MAC per sample) over the kernel time against the fp32 peak; for the
+            # QAT kernel not a utilisation (its forward products run on the bf16 pipe)
+            "fp32_equivalent": {"achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "ratio": flop / k / 1e12 / FP32_PEAK_TFLOPS},
             "traffic": pmc_bytes("k_gen_bwd_mfma<%s,true,false>" % ("true" if qat else "false")) if default_shape(ctx) else None,
             "flop_per_sample": 2 * (GEN_FWD_MAC + GEN_BWD_MAC), "kernel_ms": k * 1e3}
     if qat:
@@ -430,8 +461,22 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
             "flop_per_sample": 2 * GEN_FWD_MAC + (0 if qat else PA_FLOP), "kernel_ms": k * 1e3,
             "chain_frac": flop / t / 1e12 / FP32_PEAK_TFLOPS}
     if qat:
-        roof["note"] = ("chain_frac credits 3,208 flop/sample over the whole chain; it executes 2 x (960 + 1,472 + 1,504) + 200 = 8,072 "
-                        "(the abs-max passes recompute the layers below the scale they produce), so its ceiling is 3,208 / 8,072 = 0.40 of peak")
+        # The QAT forward kernels evaluate the layers as exact digit products on the bf16 matrix cores (12 MFMAs of 16 cycles per
+        # tile), which leaves the matrix pipe mostly idle by design; what bounds them is the issue port of the SIMDs (quantisers,
+        # digit split, LeakyReLU, FC3, tanh on the vector ALU).  frac = cycles the kernel's vector instructions hold that port over
+        # the measured kernel cycles; the matrix-pipe share and the fp32-equivalent rate (credited flops over the kernel time
+        # against the fp32 peak: a speed-up measure, not a utilisation) stand beside it.
+        matrix, issue, cyc = simd_time_fracs(GEN_QAT_FWD_P4, n / 64.0, k)
+        ginst = (GEN_QAT_FWD_P4["valu"] + GEN_QAT_FWD_P4["bf16"]) * (n / 64.0) / k / 1e9
+        roof.update({"bound": "valu-issue", "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s",
+                     "frac": issue,
+                     "frac_definition": "vector issue time of one launch (579 VALU + 48 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
+                                        "each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
+                     "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
+                     "fp32_equivalent": {"achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "ratio": kflop / k / 1e12 / FP32_PEAK_TFLOPS}})
+        roof["note"] = ("chain_frac credits 3,208 flop/sample over the whole chain against the fp32 peak; the chain executes the layers "
+                        "below each scale again in its abs-max passes (2 x (960 + 1,472 + 1,504) + 200 = 8,072 flop/sample)")
         # the one-kernel form of the QAT chain (tap assembly, three layers, the four quantisers, PA twin) with the scales of this
         # batch already known: what dpd_gen_pa_forward(qat=1) runs; timed on its own here, kernel only
         from dpd_amd import _lib as L
@@ -459,8 +504,13 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         e1.record()
         torch.cuda.synchronize()
         kf = e0.elapsed_time(e1) / 10 * 1e-3
+        fmatrix, fissue, fcyc = simd_time_fracs(GEN_QAT_FWD_PA, n / 64.0, kf)
         roof["fused_qat_kernel"] = {"kernel": "k_gen_fwd_mfma<true,4,3>: tap assembly + QAT generator (quantisers on chip, scales given) + PA twin in one kernel",
-                                    "kernel_ms": kf * 1e3, "achieved": flop / kf / 1e12, "frac": flop / kf / 1e12 / FP32_PEAK_TFLOPS,
+                                    "kernel_ms": kf * 1e3, "bound": "valu-issue", "frac": fissue,
+                                    "frac_definition": "as above with 625 VALU + 48 bf16 MFMA wave-instructions per 64 samples",
+                                    "matrix_pipe_frac": fmatrix, "cycles_per_64_samples": fcyc,
+                                    "fp32_equivalent": {"achieved": flop / kf / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                                        "ratio": flop / kf / 1e12 / FP32_PEAK_TFLOPS},
                                     "flop_per_sample": 2 * GEN_FWD_MAC + PA_FLOP}
     return dt, roof, {"y_rms": float(y[0].pow(2).mean().sqrt().item())}
 
@@ -487,8 +537,18 @@ def run_gen_pa_train(ctx, args, steps, warmup):
     k = kt.avg_seconds()
     n = ctx.rows * (ctx.seq - 5)
     flop = (2.0 * (GEN_FWD_MAC + GEN_BWD_MAC) + PA_FLOP + PA_BWD_FLOP) * n
-    roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma<QAT,PA>: tap assembly + generator + quantiser + PA twin + MSE + PA adjoint + generator backward",
-            "achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": flop / k / 1e12 / FP32_PEAK_TFLOPS,
+    # a chunk of the chain kernel advances by 56 PA outputs (its two tile pairs overlap by the PA memory): rows of 1,020 PA
+    # outputs take 19 chunks
+    chunks = ctx.rows * float(-(-(ctx.seq - 9) // 56))
+    matrix, issue, cyc = simd_time_fracs(GEN_QAT_BWD_PA, chunks, k)
+    roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma<true,true,true>: tap assembly + generator (FC1, FC2 as exact digit products on the bf16 MFMA) + "
+                                       "quantiser + PA twin + MSE + PA adjoint + generator backward (fp32 MFMA)",
+            "achieved": matrix * FP32_PEAK_TFLOPS, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": matrix,
+            "frac_definition": "matrix-pipe utilisation: MFMA cycles of one launch (128 fp32 16x16x4 at 32 cycles + 48 bf16 16x16x32 at 16 per "
+                               "chunk of 56 PA outputs) / measured kernel cycles per SIMD",
+            "issue_frac": issue, "cycles_per_chunk": cyc,
+            "fp32_equivalent": {"achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                "ratio": flop / k / 1e12 / FP32_PEAK_TFLOPS},
             "traffic": pmc_bytes("k_gen_bwd_mfma<true,true,true>") if default_shape(ctx) else None,
             "flop_per_sample": 2 * (GEN_FWD_MAC + GEN_BWD_MAC) + PA_FLOP + PA_BWD_FLOP, "kernel_ms": k * 1e3}
     return dt, roof, {"loss": float(step.grads[1554].item())}
