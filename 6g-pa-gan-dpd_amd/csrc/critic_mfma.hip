@@ -1763,14 +1763,10 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         tile = tq.tile();
         fetch(tile);
         f32x4 m1[4], m2[2], m3;
-        // two instructions per mask: the bit, sign-extended to a full word, selects between the bit
-        // patterns of 1.0 and of the slope
-        auto unpack = [&](int k) {
-            const int sel = __builtin_amdgcn_sbfe((int)bits, k, 1);
-            float m;   // (sel & 1.0) | (~sel & slope); the compiler does not form this instruction by itself
-            asm("v_bfi_b32 %0, %1, 1.0, %2" : "=v"(m) : "v"(sel), "s"(slope));
-            return m;
-        };
+        // the mask of a neuron from its bit.  (A hand-written v_bfi_b32 on the sign-extended bit is one instruction
+        // shorter, but an instruction inside an asm statement is invisible to the compiler's matrix-instruction hazard
+        // handling, and the previous tile's last MFMAs may still be executing here.)
+        auto unpack = [&](int k) { return (bits >> k) & 1u ? 1.f : slope; };
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll

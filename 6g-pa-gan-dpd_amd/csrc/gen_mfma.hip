@@ -55,7 +55,13 @@ static_assert((size_t)WAVES * BWD_WORDS * sizeof(float) <= 65536, "static LDS of
 // backward in the digit form: the five series a second time, as digit words (FC1 operands), between the series and the
 // tile buffers; the series themselves then hold the quantised integers as floats (the x operand of dW1)
 constexpr int DSER_WORDS = 356;
+// split form: words B lie a multiple of 64 words behind words A, so that one ds_read2st64_b32 fetches both
+constexpr int SPB_FWD = 704, SPB_BWD = 384;
+constexpr int FWD_ROW_SP3 = 1068;       // words per wave of the forward kernel in the split form (5 + 704 + 356, rounded up)
+static_assert(SER_BASE0 + SPB_FWD >= SER_WORDS && SER_BASE0 + SPB_FWD + DSER_WORDS <= FWD_ROW_SP3, "words B behind the series region");
 static_assert((size_t)WAVES * (BWD_WORDS + DSER_WORDS) * sizeof(float) <= 65536, "63.9 KiB, two workgroups per CU");
+// (the split form of the float backward keeps two more sets, words A and B: 69.9 KiB of static LDS, two workgroups per CU)
+static_assert((size_t)2 * WAVES * (BWD_WORDS + SPB_BWD + DSER_WORDS) * sizeof(float) <= 160 * 1024, "two workgroups per CU");
 
 #ifdef ABL_NO_MFMA      // experiment (timing only, results are wrong): every matrix instruction dropped, its dependencies kept
 DEV f32x4 mfma4(float a, float b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
@@ -145,13 +151,49 @@ DEV void commit_series_digits(float *ser, float *dser, const ChunkIQ &c, int lan
         }
     }
 }
+DEV void split_words(float x, float &a, float &b);
+// Split form of the float backward: the values themselves in the series (the x operand of dW1), their words A and B (see
+// split_words) in two more sets of series.
+DEV void commit_series_split(float *ser, float *aser, float *bser, const ChunkIQ &c, int lane) {
+#pragma unroll
+    for (int rep = 0; rep < 2; ++rep) {
+        int tau = lane + 64 * rep;
+        if (rep == 1 && lane >= 5) break;
+        const float2 v = c.p[rep];
+        const float e = sqrtf(v.x * v.x + v.y * v.y);
+        const float e2 = e * e;
+        const float x[5] = {v.x, v.y, e, e2, e2 * e2};
+        float *p = ser + SER_BASE0 + tau;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float a, b;
+            split_words(x[k], a, b);
+            p[k * SER_STRIDE] = x[k];
+            aser[tau + k * SER_STRIDE] = a;
+            bser[tau + k * SER_STRIDE] = b;
+        }
+    }
+}
 // One time point: derive its five series values and park them at position tau of the chunk's series.
 // DIG (QAT forward on the bf16 matrix cores): a series word holds the two bf16 digits of the quantised integer.
-template <bool QAT, bool DIG = false>
+DEV void split_words(float x, float &a, float &b);
+template <bool QAT, bool DIG = false, bool SP3 = false>
 DEV void commit_point(float *ser, float2 v, int tau, QS s0) {
     float e = sqrtf(v.x * v.x + v.y * v.y);
     float e2 = e * e;
     float e4 = e2 * e2;
+    if (SP3) {           // float generator, split form: word A in the series, word B in the second set behind them
+        const float x[5] = {v.x, v.y, e, e2, e4};
+        float *p = ser + SER_BASE0 + tau, *p2 = p + SPB_FWD;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float a, b;
+            split_words(x[k], a, b);
+            p[k * SER_STRIDE] = a;
+            p2[k * SER_STRIDE] = b;
+        }
+        return;
+    }
     if (DIG) {
         const f32x4 qv = q16x4(f32x4{v.x, v.y, e, e2}, s0);
         v.x = digit_word(qv[0]); v.y = digit_word(qv[1]); e = digit_word(qv[2]); e2 = digit_word(qv[3]);
@@ -393,6 +435,111 @@ DEV float digit_word(float q) {
     return __builtin_bit_cast(float, __builtin_amdgcn_perm(u, __builtin_bit_cast(unsigned, l), 0x07060302u));
 }
 
+// ---- float generator on the bf16 matrix cores: three-way split operands ------------------------------------------
+// An fp32 value is the sum of three bf16 numbers exactly: hi = its upper 16 bits, mid = the upper 16 bits of what hi
+// leaves, lo = the rest (at most 8 significant bits: truncation is exact at every step).  A product of two such sums to
+// fp32 accuracy is six bf16 products (mm, lh, hl, mh, hm, hh into one fp32 accumulator, small terms first; the three
+// dropped ones are below 2^-24 of the product), as in the critic kernels.  For FC1 (K = 32 slots) and FC2 (K = 32
+// neurons) of the float generator that is 18 v_mfma_f32_16x16x32_bf16 per tile, with VALU work issuing beside them,
+// instead of 24 v_mfma_f32_16x16x4_f32 during which nothing else issues; the biases start the accumulators.  A series
+// point is kept in LDS as two words: A = hi << 16 | mid, B = the rest as a float (its upper half is lo).
+#ifndef GEN_F32_SPLIT3
+#define GEN_F32_SPLIT3 1
+#endif
+// GEN_SPLIT_PK = 1 writes the two subtractions of a split step as one two-element vector subtraction (v_pk_add_f32 with
+// negated operand: 33 fewer instructions per chunk).  This compiler (ROCm 7.2) then emits byte permutes that take both
+// halves from the first element (v_perm_b32 d, a, a) and the float generator fails its golden test: off.
+#ifndef GEN_SPLIT_PK
+#define GEN_SPLIT_PK 0
+#endif
+DEV void split_words(float x, float &a, float &b) {
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
+    const unsigned v = __builtin_bit_cast(unsigned, r1);
+    b = r1 - __builtin_bit_cast(float, v & 0xffff0000u);
+    a = __builtin_bit_cast(float, __builtin_amdgcn_perm(u, v, 0x07060302u));
+}
+// two values -> their hi, mid and lo terms as bf16 pairs (first value in the lower half)
+DEV void split_pair3(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) {
+    const unsigned u0 = __builtin_bit_cast(unsigned, x0), u1 = __builtin_bit_cast(unsigned, x1);
+    h = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
+#if GEN_SPLIT_PK
+    // the two subtractions of a step as one packed instruction
+    const f32x2 r = f32x2{x0, x1} - f32x2{__builtin_bit_cast(float, u0 & 0xffff0000u), __builtin_bit_cast(float, u1 & 0xffff0000u)};
+    const unsigned v0 = __builtin_bit_cast(unsigned, r[0]), v1 = __builtin_bit_cast(unsigned, r[1]);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const f32x2 q = r - f32x2{__builtin_bit_cast(float, v0 & 0xffff0000u), __builtin_bit_cast(float, v1 & 0xffff0000u)};
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q[1]), __builtin_bit_cast(unsigned, q[0]), 0x07060302u);
+#else
+    const float r0 = x0 - __builtin_bit_cast(float, u0 & 0xffff0000u), r1 = x1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+    const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
+    m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
+    const float q0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+    l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
+#endif
+}
+struct Split3 {          // eight values per lane as three bf16 operands
+    u32x4 h, m, l;
+};
+DEV void split8(Split3 &o, const f32x4 &x0, const f32x4 &x1) {
+    unsigned h[4], m[4], l[4];
+    split_pair3(x0[0], x0[1], h[0], m[0], l[0]);
+    split_pair3(x0[2], x0[3], h[1], m[1], l[1]);
+    split_pair3(x1[0], x1[1], h[2], m[2], l[2]);
+    split_pair3(x1[2], x1[3], h[3], m[3], l[3]);
+    o.h = u32x4{h[0], h[1], h[2], h[3]};
+    o.m = u32x4{m[0], m[1], m[2], m[3]};
+    o.l = u32x4{l[0], l[1], l[2], l[3]};
+}
+// c + a x b to fp32 accuracy
+DEV f32x4 mfma_split3(const Split3 &a, const Split3 &b, f32x4 c) {
+    c = mfma_bf(a.m, b.m, c);
+    c = mfma_bf(a.l, b.h, c);
+    c = mfma_bf(a.h, b.l, c);
+    c = mfma_bf(a.m, b.h, c);
+    c = mfma_bf(a.h, b.m, c);
+    return mfma_bf(a.h, b.h, c);
+}
+// Split form of the forward weights.  A1[t]: lane (g, j) holds row 16 t + j of W1 at slots 8 g .. 8 g + 7 (slot = 6 *
+// series + tap; slots 30 and 31 zero); A2: row j of W2 at k = (e < 4: neuron 4 g + e, else neuron 16 + 4 g + e - 4), which
+// is what a lane holds of h1; b1[t][r], b2[r]: biases of the output neurons a lane holds of a result (they start the
+// accumulators).
+struct FwdSplit {
+    Split3 A1[2], A2;
+    f32x4 b1[2], b2;
+};
+DEV void load_fwd_split(FwdSplit &w, const float *__restrict__ wq, int j, int g) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int n = 16 * t + j;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ref = slot_ref(8 * g + e);
+            v[e] = ref >= 0 ? wq[G_W1 + n * 30 + ref] : 0.f;
+        }
+        split8(w.A1[t], f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+#pragma unroll
+        for (int r = 0; r < 4; ++r) w.b1[t][r] = wq[G_B1 + 16 * t + 4 * g + r];
+    }
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = wq[G_W2 + j * 32 + (e < 4 ? 4 * g + e : 16 + 4 * g + (e - 4))];
+    split8(w.A2, f32x4{v[0], v[1], v[2], v[3]}, f32x4{v[4], v[5], v[6], v[7]});
+#pragma unroll
+    for (int r = 0; r < 4; ++r) w.b2[r] = wq[G_B2 + 4 * g + r];
+}
+// the eight (A, B) word pairs a lane reads for FC1 -> the three operands
+DEV void split_operand(Split3 &x, const float (&a)[8], const float (&b)[8]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const unsigned a0 = __builtin_bit_cast(unsigned, a[2 * i]), a1 = __builtin_bit_cast(unsigned, a[2 * i + 1]);
+        x.h[i] = __builtin_amdgcn_perm(a1, a0, 0x07060302u);
+        x.m[i] = __builtin_amdgcn_perm(a1, a0, 0x05040100u);
+        x.l[i] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b[2 * i + 1]), __builtin_bit_cast(unsigned, b[2 * i]), 0x07060302u);
+    }
+}
+
 // LeakyReLU of a quad without a comparison: max(z, slope z) for slope <= 1, min(z, slope z) above,
 // as the median of (z, slope z, +-inf); the product is the one the comparing form selects
 template <bool ASM = true>
@@ -477,19 +624,22 @@ struct PaArgs {
 // packed FMAs.  3 ("carry"): a wave walks whole rows (unit == chunks per row), chunks do not overlap: the last M - 1
 // generator outputs of a chunk stay in LDS for the next chunk of the row, whose lanes then evaluate the PA outputs
 // t0 - 4 .. t0 + 59.  No generator output is computed twice; the host picks it when the rows fill the waves evenly.
-// (the digit form with the PA twin needs a few registers more than four waves per SIMD leave: three there)
+// (the bf16 forms with the PA twin need a few registers more than four waves per SIMD leave: three there)
 #ifndef FWD_WAVES_DIGITS_PA
 #define FWD_WAVES_DIGITS_PA 3
 #endif
 template <bool QAT, int DEPTH, int PAV>
-__global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? FWD_WAVES_DIGITS_PA : FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
+__global__ __launch_bounds__(WAVES * 64, (((QAT && GEN_QAT_DIGITS) || (!QAT && GEN_F32_SPLIT3)) && PAV != 0) ? FWD_WAVES_DIGITS_PA : FWD_WAVES_PER_SIMD) void k_gen_fwd_mfma(const float2 *__restrict__ iq, int64_t S, int64_t L,
                                                              int64_t cpr, int64_t n_chunks,
                                                              const float *__restrict__ wq, float slope,
                                                              float *__restrict__ absmax, float2 *__restrict__ out,
                                                              PaArgs pa, unsigned unit) {
     constexpr bool PA = PAV != 0, PAF = PAV >= 2, CARRY = PAV == 3;
     static_assert(!PA || DEPTH == 4, "the fused chain is a final forward");
-    __shared__ float lds[WAVES][SER_WORDS];
+    constexpr bool DIG = QAT && GEN_QAT_DIGITS;       // QAT: exact digit products on the bf16 matrix cores
+    constexpr bool SP3 = !QAT && GEN_F32_SPLIT3;      // float: three-way split products on the bf16 matrix cores
+    constexpr bool BF = DIG || SP3;                   // bf16 MFMAs in flight: no asm-wrapped VALU, no packed FMAs before row swaps
+    __shared__ float lds[WAVES][SP3 ? FWD_ROW_SP3 : SER_WORDS];
     __shared__ float pa_re[PAV == 1 ? 128 : 1], pa_im[PAV == 1 ? 128 : 1];
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: the chunk walk below runs on the scalar unit
@@ -523,9 +673,9 @@ __global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? F
     float2 *const ybuf = reinterpret_cast<float2 *>(ser + TG_W);
     constexpr int YB0 = CARRY ? 4 : 0;
     static_assert(TG_W + 2 * (CHUNK + 4) <= SER_WORDS, "room for the carried outputs");
-    constexpr bool DIG = QAT && GEN_QAT_DIGITS;
     FwdWeights w;
     FwdDigits wd;
+    FwdSplit ws;
     QS s0 = qs_one(), s1 = qs_one(), s2 = qs_one(), s3 = qs_one();
     if (QAT) {
         s0 = qs_of(absmax[0]);
@@ -534,13 +684,16 @@ __global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? F
         if (PA) s3 = qs_of(absmax[3]);
     }
     if constexpr (DIG) load_fwd_digits<(DEPTH >= 2)>(wd, wq, ser, lane, j, g, s0.s, s1.s);
+    else if constexpr (SP3) load_fwd_split(ws, wq, j, g);
     else load_fwd_weights(w, wq, j, g);
     int boff[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
-        // fp32 form: k-step s takes slot 4 s + g; digit form: the lane group's eight consecutive slots 8 g + s
-        int slot = DIG ? 8 * g + s : 4 * s + g;
-        boff[s] = 4 * ((DIG && slot >= 30 ? ZERO_W : slot_word(slot)) + (slot < 30 ? j : 0));
+        // fp32 form: k-step s takes slot 4 s + g; bf16 forms: the lane group's eight consecutive slots 8 g + s
+        int slot = BF ? 8 * g + s : 4 * s + g;
+        // split form: the two padding slots read the words of a real slot (their weights are zero, the words finite)
+        if (SP3) boff[s] = 4 * (slot_word(slot < 30 ? slot : 29) + j);
+        else boff[s] = 4 * ((DIG && slot >= 30 ? ZERO_W : slot_word(slot)) + (slot < 30 ? j : 0));
     }
     f32x2 w3p[4];     // (W3[0][4g + r], W3[1][4g + r]): FC3 runs on the VALU
 #pragma unroll
@@ -553,10 +706,24 @@ __global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? F
     struct Tile {
         f32x4 a0, a1, ha, hb, c0, c1, h2;
         u32x4 xh, xl;          // digit form: the tile's h1 as FC2 operands
+        Split3 xs;             // split form: the same
     };
     auto S1 = [&](Tile &t, int c) {
         t.a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30 (fp32 form) or with the scale (digit form)
         t.a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP3) {
+            float a[8], b[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a[e] = *reinterpret_cast<const float *>(ser_b + boff[e] + 64 * c);
+                b[e] = *reinterpret_cast<const float *>(ser_b + boff[e] + 64 * c + 4 * SPB_FWD);
+            }
+            Split3 x;
+            split_operand(x, a, b);
+            t.a0 = mfma_split3(ws.A1[0], x, ws.b1[0]);
+            t.a1 = mfma_split3(ws.A1[1], x, ws.b1[1]);
+            return;
+        }
         if constexpr (DIG) {
             unsigned d[8];
 #pragma unroll
@@ -608,7 +775,11 @@ __global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? F
             extremes(t.a0, t.a1, valid, full);
             return;
         }
-        const f32x4 x0 = lrelu4<!DIG>(t.a0, slope), x1 = lrelu4<!DIG>(t.a1, slope);
+        const f32x4 x0 = lrelu4<!BF>(t.a0, slope), x1 = lrelu4<!BF>(t.a1, slope);
+        if constexpr (SP3) {
+            if (DEPTH >= 2) split8(t.xs, x0, x1);
+            return;
+        }
         if constexpr (DIG && DEPTH >= 2) {
             const f32x4 q0 = q16x4(x0, s1), q1 = q16x4(x1, s1);
             unsigned dh[4], dl[4];
@@ -632,6 +803,10 @@ __global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? F
             t.c0 = mfma_digits(wd.A2h, wd.A2l, t.xh, t.xl, f32x4{0.f, 0.f, 0.f, 0.f});
             return;
         }
+        if constexpr (SP3) {
+            t.c0 = mfma_split3(ws.A2, t.xs, ws.b2);
+            return;
+        }
         t.c0 = w.bias2;
         t.c1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -643,19 +818,33 @@ __global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? F
     auto V2 = [&](Tile &t, bool valid, bool full) {
         f32x4 z2;
         if constexpr (DIG) z2 = __builtin_elementwise_fma(t.c0, wd.sc2, wd.b2);
-        else z2 = add4<!DIG>(t.c0, t.c1);
+        else if constexpr (SP3) z2 = t.c0;
+        else z2 = add4(t.c0, t.c1);
         if (QAT && DEPTH == 2 && slope >= 0.f) {
             extremes(z2, z2, valid, full);
             return;
         }
-        const f32x4 x = lrelu4<!DIG>(z2, slope);
-        t.h2 = (QAT && DEPTH >= 3) ? fq16x4<!DIG>(x, s2) : x;
+        const f32x4 x = lrelu4<!BF>(z2, slope);
+        t.h2 = (QAT && DEPTH >= 3) ? fq16x4<!BF>(x, s2) : x;
         if (QAT && DEPTH == 2) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) amax = fmaxf(amax, valid ? fabsf(x[r]) : 0.f);
         }
     };
 #define PHASE() __builtin_amdgcn_sched_barrier(0)
+    // bf16 forms: a matrix instruction occupies its pipe for 16 cycles but the issue port only for a few, so the VALU
+    // stage that shares a phase with an MFMA stage is spread between the MFMAs (NV vector instructions after each of NM
+    // matrix instructions) instead of following them as a block; the fp32 MFMA blocks the port, nothing to gain there
+#ifndef GEN_MIX
+#define GEN_MIX 1
+#endif
+#define MIX(NM, NV)                                                  \
+    if constexpr (BF && GEN_MIX) {                                   \
+        _Pragma("unroll") for (int i_ = 0; i_ < (NM); ++i_) {        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       \
+            __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);    \
+        }                                                            \
+    }
 
     // A wave walks through units of `unit` consecutive chunks (units dealt round robin over the waves; all of
     // this is scalar).  A chunk needs 69 time points; consecutive chunks of a row share the last
@@ -682,14 +871,15 @@ __global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? F
     if (chunk < n_chunks32) fetch(row, pos, true);
     while (chunk < n_chunks32) {
         if (fresh) {
-            if (lane < H) commit_point<QAT, DIG>(ser, pre_h, lane, s0);
+            if (lane < H) commit_point<QAT, DIG, SP3>(ser, pre_h, lane, s0);
         } else {
             for (int c = lane; c < 5 * H; c += 64) {
                 const int type = c / H, w0 = SER_BASE0 + SER_STRIDE * type + (c - type * H);
                 ser[w0] = ser[w0 + chunk_step];
+                if (SP3) ser[w0 + SPB_FWD] = ser[w0 + SPB_FWD + chunk_step];
             }
         }
-        if (lane < chunk_step) commit_point<QAT, DIG>(ser, pre, H + lane, s0);
+        if (lane < chunk_step) commit_point<QAT, DIG, SP3>(ser, pre, H + lane, s0);
         const int64_t t0_cur = (int64_t)pos * chunk_step, row_cur = row;
         // next chunk of this wave
         if (++k_in_unit < unit) {
@@ -722,18 +912,25 @@ __global__ __launch_bounds__(WAVES * 64, (QAT && GEN_QAT_DIGITS && PAV != 0) ? F
             PHASE();
             S1(B, cB);
             V1(A, vA, fA);
+            if constexpr (BF && GEN_MIX) {        // the operand reads and their byte permutes first
+                __builtin_amdgcn_sched_group_barrier(0x100, SP3 ? 16 : 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, SP3 ? 12 : 8, 0);
+            }
+            MIX(SP3 ? 12 : 8, SP3 ? 4 : 6)
             PHASE();
             if (DEPTH >= 2) {
                 S2(A);
                 V1(B, vB, fB);
+                MIX(SP3 ? 6 : 4, SP3 ? 8 : 12)
                 PHASE();
                 S2(B);
                 V2(A, vA, fA);
+                MIX(SP3 ? 6 : 4, 3)
                 PHASE();
                 if (DEPTH >= 3) {
                     V2(B, vB, fB);
                     // lane (g, j): output g & 1 of sample j of tile g >> 1
-                    float y = tanh_f32(fc3_pair<!DIG>(w3p, b3k, A.h2, B.h2));
+                    float y = tanh_f32(fc3_pair<!BF>(w3p, b3k, A.h2, B.h2));
                     const int tl = 32 * p + 16 * (g >> 1) + j;          // output index inside the chunk
                     const bool in_row = tl < rem;                        // rem: outputs left in the row from t0_cur (scalar)
                     if (QAT && !PA) amax = fmaxf(amax, in_row ? fabsf(y) : 0.f);
@@ -906,9 +1103,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // DIG: FC1 and FC2 of the forward half as digit products on the bf16 matrix cores (see the note at mfma_digits); the
     // backward half keeps the fp32 MFMA.  No asm-wrapped VALU instructions and no packed FMAs in front of row swaps then.
     constexpr bool DIG = QAT && GEN_QAT_DIGITS;
-    constexpr int WAVE_WORDS = BWD_WORDS + (DIG ? DSER_WORDS : 0);
-    constexpr int DSER_W = SER_WORDS;                              // digit series (DIG only)
-    constexpr int GZ_W = SER_WORDS + (DIG ? DSER_WORDS : 0);       // + TILE_W * buffer (these two shadow the namespace-scope ones)
+    // SP3: FC1 and FC2 of the float generator's forward half as three-way split products on the bf16 matrix cores
+    constexpr bool SP3 = !QAT && GEN_F32_SPLIT3;
+    constexpr bool BF = DIG || SP3;
+    constexpr int EXTRA_WORDS = DIG ? DSER_WORDS : SP3 ? SPB_BWD + DSER_WORDS : 0;
+    constexpr int WAVE_WORDS = BWD_WORDS + EXTRA_WORDS;
+    constexpr int DSER_W = SER_WORDS;                              // digit series (DIG) / words A then words B (SP3)
+    constexpr int GZ_W = SER_WORDS + EXTRA_WORDS;                  // + TILE_W * buffer (these two shadow the namespace-scope ones)
     constexpr int H1_W = GZ_W + 16 * P32;
     __shared__ __attribute__((aligned(16))) float lds[WAVES * WAVE_WORDS];   // static: addresses fold into the instructions
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
@@ -930,7 +1131,9 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     }
     FwdWeights w;
     FwdDigits wd;
+    FwdSplit ws;
     if constexpr (DIG) load_fwd_digits<true>(wd, wq, ser + GZ_W, lane, j, g, s0.s, s1.s);
+    else if constexpr (SP3) load_fwd_split(ws, wq, j, g);
     else load_fwd_weights(w, wq, j, g);
     float A2T[2][4];  // W2[4g + r][16t + i]
 #pragma unroll
@@ -950,8 +1153,9 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #pragma unroll
     for (int s = 0; s < 8; ++s) {
         // fp32 form: k-step s takes slot 4 s + g; digit form: the lane group's eight consecutive slots 8 g + s, digit series
-        int slot = DIG ? 8 * g + s : 4 * s + g;
+        int slot = BF ? 8 * g + s : 4 * s + g;
         if (DIG) boff[s] = 4 * (slot >= 30 ? ZERO_W : DSER_W + slot_word(slot) - SER_BASE0 + j);
+        else if (SP3) boff[s] = 4 * (DSER_W + slot_word(slot < 30 ? slot : 29) - SER_BASE0 + j);   // padding slots: finite words, zero weights
         else boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
     // dW1 A operand: lane (i = j, g) reads slot 16u + i of sample 4q + g
@@ -993,20 +1197,31 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     struct Tile {
         f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, gz2, e0, e1;
         u32x4 xh, xl;          // digit form: the tile's h1 as FC2 operands (ha, hb, c1 unused then)
+        Split3 xs;             // split form: the same
     };
     // FC1 operands are fetched from LDS one stage before the MFMAs that use them.  A tile is named by the
     // byte offset of its first sample inside the chunk's series (64 * tile, or 4 * (28 * pair + 16 * half) in
     // the chain, whose pairs overlap)
     struct Fc1Operand {
-        float v[8];
+        float v[8], b[8];      // b: words B of the split form
     };
     auto F1 = [&](Fc1Operand &b, int toff) {
 #pragma unroll
-        for (int s = 0; s < 8; ++s) b.v[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + toff);
+        for (int s = 0; s < 8; ++s) {
+            b.v[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + toff);
+            if (SP3) b.b[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + toff + 4 * SPB_BWD);
+        }
     };
     auto S1 = [&](f32x4 &a0, f32x4 &a1, const Fc1Operand &b) {
         a0 = f32x4{0.f, 0.f, 0.f, 0.f};   // b1 enters through slot 30 (fp32 form) or with the scales (digit form)
         a1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (SP3) {
+            Split3 x;
+            split_operand(x, b.v, b.b);
+            a0 = mfma_split3(ws.A1[0], x, ws.b1[0]);
+            a1 = mfma_split3(ws.A1[1], x, ws.b1[1]);
+            return;
+        }
         if constexpr (DIG) {
             u32x4 xh, xl;
 #pragma unroll
@@ -1035,9 +1250,13 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             t.m1a[r] = t.a0[r] > 0.f ? 1.f : slope;
             t.m1b[r] = t.a1[r] > 0.f ? 1.f : slope;
         }
-        t.a0 = mul4<!DIG>(t.a0, t.m1a);
-        t.a1 = mul4<!DIG>(t.a1, t.m1b);
-        if constexpr (DIG) {
+        t.a0 = mul4<!BF>(t.a0, t.m1a);
+        t.a1 = mul4<!BF>(t.a1, t.m1b);
+        if constexpr (SP3) {
+            t.ha = t.a0;
+            t.hb = t.a1;
+            split8(t.xs, t.ha, t.hb);
+        } else if constexpr (DIG) {
             // h1 as integers: digits for FC2, the integers themselves (as floats) for dW2, which is scaled once at the end
             t.ha = q16x4(t.a0, s1);
             t.hb = q16x4(t.a1, s1);
@@ -1061,6 +1280,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             t.c0 = mfma_digits(wd.A2h, wd.A2l, t.xh, t.xl, f32x4{0.f, 0.f, 0.f, 0.f});
             return;
         }
+        if constexpr (SP3) {
+            t.c0 = mfma_split3(ws.A2, t.xs, ws.b2);
+            return;
+        }
         t.c0 = w.bias2;
         t.c1 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1071,11 +1294,11 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     };
     auto V2 = [&](Tile &t) {
         if constexpr (DIG) t.c0 = __builtin_elementwise_fma(t.c0, wd.sc2, wd.b2);
-        else t.c0 = add4(t.c0, t.c1);
+        else if constexpr (!SP3) t.c0 = add4(t.c0, t.c1);
 #pragma unroll
         for (int r = 0; r < 4; ++r) t.m2[r] = t.c0[r] > 0.f ? 1.f : slope;
-        t.c0 = mul4<!DIG>(t.c0, t.m2);
-        t.h2 = QAT ? fq16x4<!DIG>(t.c0, s2) : t.c0;
+        t.c0 = mul4<!BF>(t.c0, t.m2);
+        t.h2 = QAT ? fq16x4<!BF>(t.c0, s2) : t.c0;
     };
     // Output stage of a tile pair: 32 samples x 2 outputs = one (sample, output) per lane.  Lane (g, j)
     // takes output g & 1 of sample j of tile g >> 1, so tanh, loss and gz3 are evaluated once each; gz3
@@ -1162,7 +1385,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         return __builtin_fmaf(2.f * (c ? ui : ur), b, c ? ai : ar);
     };
     auto V3P = [&](Tile &A, Tile &B, int p, int64_t t0_cur) {
-        const float y = tanh_f32(fc3_pair<!DIG>(w3p, b3k, A.h2, B.h2));
+        const float y = tanh_f32(fc3_pair<!BF>(w3p, b3k, A.h2, B.h2));
         float gup;
         if constexpr (PA) {
             gup = pa_stage(y, p, t0_cur);
@@ -1197,10 +1420,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         dW3[1] = __builtin_elementwise_fma(a1v, A.h2, dW3[1]);
         dW3[0] = __builtin_elementwise_fma(b0v, B.h2, dW3[0]);
         dW3[1] = __builtin_elementwise_fma(b1v, B.h2, dW3[1]);
-        A.gz2 = mul4<!DIG>(__builtin_elementwise_fma(w3r[1], a1v, mul4<!DIG>(w3r[0], a0v)), A.m2);
-        B.gz2 = mul4<!DIG>(__builtin_elementwise_fma(w3r[1], b1v, mul4<!DIG>(w3r[0], b0v)), B.m2);
-        db2 = add4<!DIG>(db2, A.gz2);
-        db2 = add4<!DIG>(db2, B.gz2);
+        A.gz2 = mul4<!BF>(__builtin_elementwise_fma(w3r[1], a1v, mul4<!BF>(w3r[0], a0v)), A.m2);
+        B.gz2 = mul4<!BF>(__builtin_elementwise_fma(w3r[1], b1v, mul4<!BF>(w3r[0], b0v)), B.m2);
+        db2 = add4<!BF>(db2, A.gz2);
+        db2 = add4<!BF>(db2, B.gz2);
     };
     auto V4 = [&](Tile &t, int buf) {
         *reinterpret_cast<f32x4 *>(ser_b + 4 * (GZ_W + TILE_W * buf) + wr32 + 128) = t.gz2;
@@ -1215,8 +1438,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         }
     };
     auto V5 = [&](Tile &t, int buf) {
-        t.e0 = mul4<!DIG>(t.e0, t.m1a);
-        t.e1 = mul4<!DIG>(t.e1, t.m1b);
+        t.e0 = mul4<!BF>(t.e0, t.m1a);
+        t.e1 = mul4<!BF>(t.e1, t.m1b);
         char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
         *reinterpret_cast<f32x4 *>(gz_b + wr32) = t.e0;
         *reinterpret_cast<f32x4 *>(gz_b + wr32 + 64) = t.e1;
@@ -1325,6 +1548,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         { unsigned long long now = __builtin_readcyclecounter(); tacc[17] += now - tlast; tlast = now; }
 #endif
         if constexpr (DIG) commit_series_digits(ser, ser + DSER_W, pre, lane, s0);
+        else if constexpr (SP3) commit_series_split(ser, ser + DSER_W, ser + DSER_W + SPB_BWD, pre, lane);
         else commit_series<QAT>(ser, pre, lane, s0);
         tg_lds[lane] = pre_tg;
 #ifdef ABL_TIMING
@@ -1347,6 +1571,8 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             if (lane < CSTEP && t0 + lane < LT) pre_tg = gsrc[row * LT + t0 + lane];
         }
         __builtin_amdgcn_wave_barrier();
+        // (measured: spreading the VALU stage of a phase between its bf16 MFMAs with sched_group_barrier, as the forward
+        // kernel does, is 1-2 % slower here)
         // (measured: starting FC1 of the second pair inside the output stage of the first, the one stretch
         // of a pair without MFMA work of its own, is 3% slower: the MFMAs hold up the VALU work behind them)
 #pragma unroll

@@ -49,18 +49,20 @@ PA_BWD_FLOP = 400
 # the first-layer weight gradient on v_mfma_f32_4x4x1_16b_f32 (16 x 8); the hidden-layer products (60) and the weight
 # gradients of the two inner layers (30) as three-way-split bf16 operands on v_mfma_f32_16x16x32_bf16 (16 cycles)
 CRITIC_BWD_BF16_MFMA = 90
-# k_q88_mfma, per chunk of 64 samples and wave, counted in the loop body of the compiled kernel (scratch/isa_hist.py)
-Q88_VALU_PER_CHUNK = 604
+# k_q88_mfma, per chunk of 64 samples and wave, counted in the chunk loop of the compiled kernel (scratch/isa_hist.py)
+Q88_VALU_PER_CHUNK = 633
 Q88_MFMA_PER_CHUNK = 40
 # QAT generator kernels in the digit form (fake-quantised values as two exact bf16 digits), per chunk of 64 samples and
 # wave, counted in the loop bodies of the compiled kernels (scratch/isa_hist.py): vector-ALU instructions, bf16 MFMAs
 # (v_mfma_f32_16x16x32_bf16, 16 cycles on the matrix pipe, 4 on the issue port) and fp32 MFMAs (v_mfma_f32_16x16x4_f32,
 # 32 cycles during which the SIMD issues nothing else)
-GEN_QAT_FWD_P4 = {"valu": 579, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,3,0>: last abs-max pass
-GEN_QAT_FWD_PA = {"valu": 625, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,4,3>: fused chain forward
-GEN_QAT_BWD = {"valu": 680, "bf16": 48, "fp32": 128}        # k_gen_bwd_mfma<true,true,false>: Stage-1 step
-GEN_QAT_BWD_PA = {"valu": 996, "bf16": 48, "fp32": 128}     # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
-GEN_FLOAT_BWD = {"valu": 348, "bf16": 0, "fp32": 224}       # k_gen_bwd_mfma<false,true,false>
+GEN_QAT_FWD_P4 = {"valu": 583, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,3,0>: last abs-max pass
+GEN_QAT_FWD_PA = {"valu": 628, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,4,3>: fused chain forward
+GEN_QAT_BWD = {"valu": 786, "bf16": 48, "fp32": 128}        # k_gen_bwd_mfma<true,true,false>: Stage-1 step
+GEN_QAT_BWD_PA = {"valu": 998, "bf16": 48, "fp32": 128}     # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
+# float generator: FC1 and FC2 of the forward as three-way split bf16 products (18 MFMAs per tile), backward on the fp32 MFMA
+GEN_FLOAT_FWD_PA = {"valu": 564, "bf16": 72, "fp32": 0}     # k_gen_fwd_mfma<false,4,3>: fused chain forward
+GEN_FLOAT_BWD = {"valu": 700, "bf16": 72, "fp32": 128}      # k_gen_bwd_mfma<false,true,false>
 CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + CRITIC_BWD_BF16_MFMA * 16
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
@@ -253,15 +255,16 @@ def run_stage1(ctx, args, qat, steps, warmup):
     roof = {"bound": "mfma",
             "kernel": ("k_gen_bwd_mfma<true,true,false>: tap assembly + forward (FC1, FC2 as exact digit products on the bf16 MFMA) + MSE + "
                        "backward (fp32 MFMA) (+ slab reduce)" if qat else
-                       "k_gen_bwd_mfma<false,true,false>: tap assembly + forward + MSE + backward, fp32 MFMA (+ slab reduce)"),
+                       "k_gen_bwd_mfma<false,true,false>: tap assembly + forward (FC1, FC2 as three-way split products on the bf16 MFMA, "
+                       "fp32 accuracy) + MSE + backward (fp32 MFMA) (+ slab reduce)"),
             # utilisation of the matrix pipes: cycles the kernel's MFMAs occupy them over the measured kernel cycles; `achieved`
             # = frac x the fp32 MFMA peak (the pipe that carries the bulk of those cycles)
             "achieved": matrix * FP32_PEAK_TFLOPS, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": matrix,
             "frac_definition": "matrix-pipe utilisation: MFMA cycles of one launch (fp32 16x16x4 at 32 cycles, bf16 16x16x32 at 16, "
                                "counted in the kernel's assembly) / measured kernel cycles per SIMD",
             "issue_frac": issue, "cycles_per_64_samples": cyc,
-            # algorithmic fp32 flops (2 x (1,504 + 2,048) MAC per sample) over the kernel time against the fp32 peak; for the
-            # QAT kernel not a utilisation (its forward products run on the bf16 pipe)
+            # algorithmic fp32 flops (2 x (1,504 + 2,048) MAC per sample) over the kernel time against the fp32 peak: not a
+            # utilisation (the forward products run on the bf16 pipe)
             "fp32_equivalent": {"achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "ratio": flop / k / 1e12 / FP32_PEAK_TFLOPS},
             "traffic": pmc_bytes("k_gen_bwd_mfma<%s,true,false>" % ("true" if qat else "false")) if default_shape(ctx) else None,
@@ -350,14 +353,14 @@ def q88_roof(ctx, k, eng):
         # Matrix-core form.  What bounds it is the issue port of the SIMDs: per chunk of 64 samples a wave issues
         # Q88_VALU_PER_CHUNK vector-ALU instructions (requantisation, LeakyReLU, digit split, feature planes; counted in the
         # kernel's ISA, scratch/isa_hist.py) and 40 MFMAs.  A wave64 VALU instruction holds the port of its SIMD for 4 cycles,
-        # an int8 MFMA for 4 of its 16: the floor is (634 x 4 + 40 x 4) cycles per chunk and SIMD.  frac = that floor over the
+        # an int8 MFMA for 4 of its 16: the floor is (633 x 4 + 40 x 4) cycles per chunk and SIMD.  frac = that floor over the
         # measured kernel time; the matrix pipe and HBM are reported beside it and are far from their peaks.
         chunks_per_simd = n / 64.0 / N_SIMD
         issue_s = chunks_per_simd * (Q88_VALU_PER_CHUNK * 4 + Q88_MFMA_PER_CHUNK * 4) / CLOCK_HZ
         ginst = (Q88_VALU_PER_CHUNK + Q88_MFMA_PER_CHUNK) * (n / 64.0) / k / 1e9
         peak = N_SIMD * CLOCK_HZ / 4 / 1e9
         return {"bound": "valu-issue", "achieved": ginst, "peak": peak, "unit": "G wave-instructions/s", "frac": issue_s / k,
-                "frac_definition": "vector issue time of one launch (634 VALU + 40 MFMA wave-instructions per 64 samples, 4 cycles each "
+                "frac_definition": "vector issue time of one launch (633 VALU + 40 MFMA wave-instructions per 64 samples, 4 cycles each "
                                    "on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
                 "kernel": "k_q88_mfma (v_mfma_i32_16x16x64_i8, int16 = two 8-bit digits, three int32 accumulators per product)",
                 "issue_floor_ms": issue_s * 1e3, "kernel_ms": k * 1e3, "valu_per_64_samples": Q88_VALU_PER_CHUNK,
@@ -454,12 +457,25 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
     flop = (2.0 * GEN_FWD_MAC + PA_FLOP) * n
     t = dt / steps / ctx.micro
     kname = ("k_gen_fwd_mfma<true,3,0>: tap assembly + QAT generator forward to the unquantised output (4th abs-max pass)" if qat else
-             "k_gen_fwd_mfma<false,4,3>: tap assembly + generator + PA twin in one kernel (whole rows per wave, outputs carried)")
+             "k_gen_fwd_mfma<false,4,3>: tap assembly + generator (FC1, FC2 as three-way split products on the bf16 MFMA, fp32 accuracy) + "
+             "PA twin in one kernel (whole rows per wave, outputs carried)")
     roof = {"bound": "mfma", "kernel": kname,
             "achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": kflop / k / 1e12 / FP32_PEAK_TFLOPS,
             "traffic": pmc_bytes("k_gen_fwd_mfma<true,3,0>" if qat else "k_gen_fwd_mfma<false,4,3>") if default_shape(ctx) else None,
             "flop_per_sample": 2 * GEN_FWD_MAC + (0 if qat else PA_FLOP), "kernel_ms": k * 1e3,
             "chain_frac": flop / t / 1e12 / FP32_PEAK_TFLOPS}
+    if not qat:
+        # float: FC1 and FC2 as three-way split products on the bf16 matrix cores (18 MFMAs of 16 cycles per tile, fp32
+        # accuracy); like the QAT form below the kernel is bound by the issue port of the SIMDs, and frac is that utilisation
+        matrix, issue, cyc = simd_time_fracs(GEN_FLOAT_FWD_PA, n / 64.0, k)
+        ginst = (GEN_FLOAT_FWD_PA["valu"] + GEN_FLOAT_FWD_PA["bf16"]) * (n / 64.0) / k / 1e9
+        roof.update({"bound": "valu-issue", "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s",
+                     "frac": issue,
+                     "frac_definition": "vector issue time of one launch (564 VALU + 72 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
+                                        "each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
+                     "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
+                     "fp32_equivalent": {"achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                         "ratio": kflop / k / 1e12 / FP32_PEAK_TFLOPS}})
     if qat:
         # The QAT forward kernels evaluate the layers as exact digit products on the bf16 matrix cores (12 MFMAs of 16 cycles per
         # tile), which leaves the matrix pipe mostly idle by design; what bounds them is the issue port of the SIMDs (quantisers,
@@ -470,7 +486,7 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         ginst = (GEN_QAT_FWD_P4["valu"] + GEN_QAT_FWD_P4["bf16"]) * (n / 64.0) / k / 1e9
         roof.update({"bound": "valu-issue", "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s",
                      "frac": issue,
-                     "frac_definition": "vector issue time of one launch (579 VALU + 48 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
+                     "frac_definition": "vector issue time of one launch (583 VALU + 48 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
                                         "each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
                      "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
                      "fp32_equivalent": {"achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -507,7 +523,7 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         fmatrix, fissue, fcyc = simd_time_fracs(GEN_QAT_FWD_PA, n / 64.0, kf)
         roof["fused_qat_kernel"] = {"kernel": "k_gen_fwd_mfma<true,4,3>: tap assembly + QAT generator (quantisers on chip, scales given) + PA twin in one kernel",
                                     "kernel_ms": kf * 1e3, "bound": "valu-issue", "frac": fissue,
-                                    "frac_definition": "as above with 625 VALU + 48 bf16 MFMA wave-instructions per 64 samples",
+                                    "frac_definition": "as above with 628 VALU + 48 bf16 MFMA wave-instructions per 64 samples",
                                     "matrix_pipe_frac": fmatrix, "cycles_per_64_samples": fcyc,
                                     "fp32_equivalent": {"achieved": flop / kf / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                         "ratio": flop / kf / 1e12 / FP32_PEAK_TFLOPS},
@@ -773,7 +789,12 @@ LABELS = {
     "spectral": "SpectralLoss forward + backward",
 }
 EXTRAS = ("stage1", "stage1_qat", "q88", "q88_stream", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral")
-DTYPE = {"q88": "int16", "q88_stream": "int16", "stage2": "f32 (critic hidden-layer products and inner weight gradients: bf16 x 3-way split, fp32 accumulate)"}
+_QAT_DT = "f32 (QAT generator forward products: exact 2-digit bf16 products of the 16-bit quantised integers, fp32 accumulate)"
+_F32_DT = "f32 (generator forward products: bf16 x 3-way split, fp32 accumulate)"
+DTYPE = {"q88": "int16", "q88_stream": "int16",
+         "stage2": "f32 (critic hidden-layer products and inner weight gradients: bf16 x 3-way split, fp32 accumulate; QAT generator "
+                   "forward products: exact 2-digit bf16 products of the 16-bit quantised integers, fp32 accumulate)",
+         "stage1": _F32_DT, "gen_pa_float": _F32_DT, "stage1_qat": _QAT_DT, "gen_pa": _QAT_DT, "gen_pa_train": _QAT_DT}
 
 
 def main():
@@ -811,7 +832,7 @@ def main():
             d, r, a = RUNNERS[name](ctx, args, 5, 2)          # (the stream workload sets its own samples per step)
             if ctx.rank == 0:
                 extra[name] = {"value": ctx.n_local * ctx.world * 5 / d, "unit": "samples/s", "ms_per_step": d / 5 * 1e3,
-                               "steps": 5, "workload": LABELS[name], "roofline": r, **a}
+                               "steps": 5, "workload": LABELS[name], "dtype": DTYPE.get(name, "f32"), "roofline": r, **a}
             ctx.n_local = n_local
         if ctx.rank == 0:
             res["extra"] = extra

@@ -32,7 +32,7 @@ if only_loop:
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             span = (labels[m.group(1)], i)
             nm = sum(1 for x in body[span[0]:span[1]] if 'v_mfma' in x)
-            if best is None or nm > best[2] or (nm == best[2] and span[1] - span[0] < best[1] - best[0]):
+            if best is None or nm > best[2] or (nm == best[2] and span[1] - span[0] > best[1] - best[0]):   # the outermost of the loops that hold the MFMAs
                 best = (span[0], span[1], nm)
     body = body[best[0]:best[1] + 1]
     print("loop lines", best)

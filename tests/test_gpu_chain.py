@@ -284,3 +284,52 @@ def test_qat_backward_repeats_bit_for_bit_under_load():
                 assert torch.equal(g, first)
     finally:
         L.call("dpd_set_option", b"gen_deterministic", 0)
+
+
+def test_float_kernels_repeat_bit_for_bit_under_load():
+    """The float generator kernels run FC1 and FC2 as three-way split products on the bf16 matrix cores, VALU work issuing
+    beside the matrix instructions: forward, fused chain and (in deterministic mode) the two fused training kernels must
+    give identical bits on repeated launches at a size that fills every SIMD."""
+    from dpd_amd import _lib as L
+    from dpd_amd.data import ofdm_rows
+    from dpd_amd.models import PADigitalTwin, TDNNGeneratorQAT
+    from dpd_amd.training import ChainStep, Stage1Step
+    B, S = 4096, 1029
+    iq = ofdm_rows(B, S, seed=79, device=DEV)
+    tgt = iq[:, 5:, :].contiguous()
+    torch.manual_seed(0)
+    gen = TDNNGeneratorQAT().to(DEV).train()
+    gen.qat_enabled = False
+    pa = PADigitalTwin().to(DEV)
+    ps = [gen.fc1.weight, gen.fc1.bias, gen.fc2.weight, gen.fc2.bias, gen.fc3.weight, gen.fc3.bias]
+    wq = torch.empty(L.GEN_NPARAM, device=DEV)
+    absmax = torch.zeros(L.GEN_NSCALE, device=DEV)
+    st = L.stream()
+    L.call("dpd_gen_prepare_weights", *(L.fptr(p.detach()) for p in ps), 0, L.fptr(wq), L.fptr(absmax), st)
+    cre, cim = pa.pa_model.coeffs_real.contiguous(), pa.pa_model.coeffs_imag.contiguous()
+    out, out2 = torch.empty(B, S - 5, 2, device=DEV), torch.empty(B, S - 5, 2, device=DEV)
+    yb = torch.empty(B, S - 9, 2, device=DEV)
+    first = None
+    for _ in range(12):
+        L.call("dpd_gen_forward", L.fptr(iq), B, S, 0, L.fptr(wq), 0.2, 0, L.fptr(absmax), L.fptr(out), 2, st)
+        L.call("dpd_gen_pa_forward", L.fptr(iq), B, S, L.fptr(wq), 0.2, 0, L.fptr(absmax), L.fptr(cre), L.fptr(cim), 4, 5,
+               L.fptr(out2), L.fptr(yb), st)
+        if first is None:
+            first = (out.clone(), yb.clone())
+        assert torch.equal(out, first[0]) and torch.equal(out2, first[0]) and torch.equal(yb, first[1])
+    L.call("dpd_set_option", b"gen_deterministic", 1)
+    try:
+        for make, target in ((lambda: Stage1Step(gen, optimizer=torch.optim.SGD(gen.parameters(), lr=0.0)), tgt),
+                             (lambda: ChainStep(gen, pa, optimizer=torch.optim.SGD(gen.parameters(), lr=0.0)),
+                              (tgt[:, 4:, :] * 31.0).contiguous())):
+            step = make()
+            ref = None
+            for _ in range(12):
+                step(iq, target)
+                g = step.grads[:L.GEN_NPARAM + 1].clone()
+                assert bool(torch.isfinite(g).all())
+                if ref is None:
+                    ref = g
+                assert torch.equal(g, ref)
+    finally:
+        L.call("dpd_set_option", b"gen_deterministic", 0)
