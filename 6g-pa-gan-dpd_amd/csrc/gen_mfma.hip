@@ -1,7 +1,9 @@
 // Generator kernels, MFMA family (gfx950): tap assembly + 30->32->16->2 forward (+ backward) fused
-// per 16-sample tile on v_mfma_f32_16x16x4_f32 (float generator, and every backward product); the forward layers of
-// the QAT generator run as exact digit products on v_mfma_f32_16x16x32_bf16 (see mfma_digits).  Reference semantics
-// as in gen_valu.hip.
+// per 16-sample tile.  Default build: every product on v_mfma_f32_16x16x32_bf16 at fp32 accuracy -- the forward layers
+// of the QAT generator as exact digit products (see mfma_digits), those of the float generator and every backward
+// product as three-way split products (see mfma_split3, outer3).  The v_mfma_f32_16x16x4_f32 formulation described
+// below is the code's other path (GEN_QAT_DIGITS = 0, GEN_F32_SPLIT3 = 0); geometry and schedule are common to both.
+// Reference semantics as in gen_valu.hip.
 //
 // Geometry.  A wave owns a chunk of 64 consecutive output samples of one IQ row (4 tiles of 16).
 // Lane l = (g = l >> 4, j = l & 15).  Every product is computed transposed, D = W * X^T, so that
@@ -385,7 +387,8 @@ DEV f32x4 fq16x4(f32x4 v, QS k) {
 // replaced by the digit split.  Same mathematical value as the reference's sum of products of dequantised numbers,
 // rounded in fewer places.  The fused training kernels use the same form for FC1 and FC2 of their forward half (identical
 // operand order, so the pre-activations equal those of the abs-max passes bit for bit); their weight gradients contract
-// the integers (series and h1, kept as floats beside the digits) and take the tensor scale once at the end of the kernel.
+// the integers (series and h1: the digits are the two terms of the left factor) and take the tensor scale once at the
+// end of the kernel.
 #ifndef GEN_QAT_DIGITS
 #define GEN_QAT_DIGITS 1
 #endif
@@ -538,6 +541,41 @@ DEV void split_operand(Split3 &x, const float (&a)[8], const float (&b)[8]) {
         x.m[i] = __builtin_amdgcn_perm(a1, a0, 0x05040100u);
         x.l[i] = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, b[2 * i + 1]), __builtin_bit_cast(unsigned, b[2 * i]), 0x07060302u);
     }
+}
+
+// ---- weight gradients on the bf16 matrix cores (backward of the bf16 forms) ---------------------------------------
+// dW = sum over the samples of a tile of (left factor) x (right factor) contracts over the lane index of both factors.
+// Their bf16 terms are parked in LDS as [sample][neuron] slots (16 rows of 64 bytes: chunk c of a row holds neurons
+// 4c..4c+3 of an even 16-neuron tile and of the next one, 8 bytes each; the chunk index is XORed with row bits 1..2 so
+// that a store group covers all banks) and read back with the transposing ds_read_b64_tr_b16: lane (kg, n) receives
+// samples 4kg..4kg+3 of neuron n.  A K = 32 instruction takes two terms per operand (k-slots 0..3 of a lane group: four
+// samples of one term, 4..7: the same samples of another), so the six products of a 16 x 16 tile are three MFMAs:
+//   [h|l] x [l|h] = hl + lh,  [h|m] x [m|h] = hm + mh,  [h|m] x [h|m] = hh + mm      (left term first)
+constexpr int SLOT_B = 1024;                // bytes of a slot
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+struct OpL { u32x4 hm, hl; };               // left factor (rows of the result): [h|m], [h|l]
+struct OpR { u32x4 hm, mh, lh; };           // right factor (columns): [h|m], [m|h], [l|h]
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+DEV u32x2 tr_read(lds_char *p) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p)); }
+DEV u32x4 cat(u32x2 a, u32x2 b) { return u32x4{a[0], a[1], b[0], b[1]}; }
+// h, m, l: byte offsets of the 8-byte pieces of the three terms (l < 0: the factor has two terms only)
+DEV void read_op(OpL &o, lds_char *tr, int h, int m, int l) {
+    const u32x2 ph = tr_read(tr + h);
+    o.hm = cat(ph, tr_read(tr + m));
+    o.hl = l >= 0 ? cat(ph, tr_read(tr + l)) : u32x4{ph[0], ph[1], 0u, 0u};
+}
+DEV void read_op(OpR &o, lds_char *tr, int h, int m, int l) {
+    const u32x2 ph = tr_read(tr + h), pm = tr_read(tr + m);
+    o.hm = cat(ph, pm);
+    o.mh = cat(pm, ph);
+    o.lh = cat(tr_read(tr + l), ph);
+}
+DEV f32x4 outer3(f32x4 acc, const OpL &a, const OpR &b) {
+    acc = mfma_bf(a.hl, b.lh, acc);
+    acc = mfma_bf(a.hm, b.mh, acc);
+    return mfma_bf(a.hm, b.hm, acc);
 }
 
 // LeakyReLU of a quad without a comparison: max(z, slope z) for slope <= 1, min(z, slope z) above,
@@ -1106,11 +1144,22 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // SP3: FC1 and FC2 of the float generator's forward half as three-way split products on the bf16 matrix cores
     constexpr bool SP3 = !QAT && GEN_F32_SPLIT3;
     constexpr bool BF = DIG || SP3;
-    constexpr int EXTRA_WORDS = DIG ? DSER_WORDS : SP3 ? SPB_BWD + DSER_WORDS : 0;
-    constexpr int WAVE_WORDS = BWD_WORDS + EXTRA_WORDS;
-    constexpr int DSER_W = SER_WORDS;                              // digit series (DIG) / words A then words B (SP3)
-    constexpr int GZ_W = SER_WORDS + EXTRA_WORDS;                  // + TILE_W * buffer (these two shadow the namespace-scope ones)
+    // OB: the weight gradients dW1 and dW2 on the bf16 matrix cores as well (see the note at outer3).  The series then hold
+    // the forward's words only (digit words, or words A with words B SPB_FWD behind them, as in the forward kernel: the x
+    // operand of dW1 is built from them), and a tile buffer is five term slots: h1 (three terms; two digits in the digit
+    // form), overwritten by gz1 once dW2 has read them, and gz2 ([h|m] in one slot, l in half of the next).
+#ifndef GEN_BWD_BF16
+#define GEN_BWD_BF16 1
+#endif
+    constexpr bool OB = BF && GEN_BWD_BF16;
+    constexpr int EXTRA_WORDS = OB ? (SP3 ? FWD_ROW_SP3 - SER_WORDS : 0) : DIG ? DSER_WORDS : SP3 ? SPB_BWD + DSER_WORDS : 0;
+    constexpr int TB_WORDS = OB ? 5 * SLOT_B / 4 : TILE_W;         // words per tile buffer
+    constexpr int WAVE_WORDS = SER_WORDS + EXTRA_WORDS + 2 * TB_WORDS;
+    constexpr int DSER_W = SER_WORDS;                              // !OB: digit series (DIG) / words A then words B (SP3)
+    constexpr int GZ_W = SER_WORDS + EXTRA_WORDS;                  // + TB_WORDS * buffer (these two shadow the namespace-scope ones)
     constexpr int H1_W = GZ_W + 16 * P32;
+    constexpr int S_H1 = 0, S_G1 = 0, S_G2 = 3 * SLOT_B;           // OB: byte offsets of the slot groups in a tile buffer
+    static_assert(WAVES * WAVE_WORDS >= WAVES * G_SLAB, "the gradient rows are combined in the staging LDS");
     __shared__ __attribute__((aligned(16))) float lds[WAVES * WAVE_WORDS];   // static: addresses fold into the instructions
     const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // scalar: chunk, row and position arithmetic run on the scalar unit
@@ -1140,6 +1189,19 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) A2T[t][r] = wq[G_W2 + (4 * g + r) * 32 + 16 * t + j];
+    // OB: the same weights as split operands.  The contraction of gh1 = W2^T gz2 runs over the 16 layer-2 neurons only, so
+    // a K = 32 instruction takes two terms of the lane group's four neurons: T2[2t] = [h|l], T2[2t + 1] = [h|m] of row tile t
+    u32x4 T2[4];
+    if constexpr (OB) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            unsigned h[2], m[2], l[2];
+            split_pair3(A2T[t][0], A2T[t][1], h[0], m[0], l[0]);
+            split_pair3(A2T[t][2], A2T[t][3], h[1], m[1], l[1]);
+            T2[2 * t] = u32x4{h[0], h[1], l[0], l[1]};
+            T2[2 * t + 1] = u32x4{h[0], h[1], m[0], m[1]};
+        }
+    }
     f32x2 w3p[4];     // (W3[0][4g + r], W3[1][4g + r]): FC3 and its input gradient run on the VALU
     f32x4 w3r[2];     // the same weights by row, for the input gradient
 #pragma unroll
@@ -1154,10 +1216,25 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     for (int s = 0; s < 8; ++s) {
         // fp32 form: k-step s takes slot 4 s + g; digit form: the lane group's eight consecutive slots 8 g + s, digit series
         int slot = BF ? 8 * g + s : 4 * s + g;
-        if (DIG) boff[s] = 4 * (slot >= 30 ? ZERO_W : DSER_W + slot_word(slot) - SER_BASE0 + j);
+        if (OB && DIG) boff[s] = 4 * ((slot >= 30 ? ZERO_W : slot_word(slot)) + (slot < 30 ? j : 0));
+        else if (OB && SP3) boff[s] = 4 * (slot_word(slot < 30 ? slot : 29) + j);
+        else if (DIG) boff[s] = 4 * (slot >= 30 ? ZERO_W : DSER_W + slot_word(slot) - SER_BASE0 + j);
         else if (SP3) boff[s] = 4 * (DSER_W + slot_word(slot < 30 ? slot : 29) - SER_BASE0 + j);   // padding slots: finite words, zero weights
         else boff[s] = 4 * (slot_word(slot) + (slot < 30 ? j : 0));
     }
+    // OB: x operand of dW1 (left factor, rows = slots): lane (kg = g, n = j) reads the words of samples 4g..4g+3 of slot
+    // 16u + j (slot 30: the constant 1 whose row is the bias gradient, slot 31: zeros; their words B are zeros)
+    int xa[2], xb[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int slot = 16 * u + j;
+        xa[u] = 4 * (slot_word(slot) + 4 * g);
+        xb[u] = slot < 30 ? xa[u] + 4 * SPB_FWD : 4 * (ZERO_W + 4 * g);
+    }
+    // OB: this lane's 16 bytes of row j of a slot (store) and the 8 bytes it points the transposing read at
+    const int tw_off = 64 * j + 16 * (g ^ ((j >> 1) & 3));
+    const int tr_row = 4 * g + (j >> 2);
+    const int tr_off = 64 * tr_row + 16 * ((j & 3) ^ ((tr_row >> 1) & 3));
     // dW1 A operand: lane (i = j, g) reads slot 16u + i of sample 4q + g
     int aoff[2];
 #pragma unroll
@@ -1198,6 +1275,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         f32x4 a0, a1, m1a, m1b, ha, hb, c0, c1, m2, h2, gz2, e0, e1;
         u32x4 xh, xl;          // digit form: the tile's h1 as FC2 operands (ha, hb, c1 unused then)
         Split3 xs;             // split form: the same
+        unsigned g2h[2], g2m[2], g2l[2];   // OB: the terms of gz2
     };
     // FC1 operands are fetched from LDS one stage before the MFMAs that use them.  A tile is named by the
     // byte offset of its first sample inside the chunk's series (64 * tile, or 4 * (28 * pair + 16 * half) in
@@ -1209,7 +1287,7 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             b.v[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + toff);
-            if (SP3) b.b[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + toff + 4 * SPB_BWD);
+            if (SP3) b.b[s] = *reinterpret_cast<const float *>(ser_b + boff[s] + toff + 4 * (OB ? SPB_FWD : SPB_BWD));
         }
     };
     auto S1 = [&](f32x4 &a0, f32x4 &a1, const Fc1Operand &b) {
@@ -1271,6 +1349,19 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             t.ha = QAT ? fq16x4(t.a0, s1) : t.a0;
             t.hb = QAT ? fq16x4(t.a1, s1) : t.a1;
         }
+        if constexpr (OB) {             // the terms of h1, the left factor of dW2
+            char *tw = ser_b + 4 * (GZ_W + TB_WORDS * buf) + tw_off;
+            if constexpr (SP3) {
+                *reinterpret_cast<u32x4 *>(tw + S_H1) = t.xs.h;
+                *reinterpret_cast<u32x4 *>(tw + S_H1 + SLOT_B) = t.xs.m;
+                *reinterpret_cast<u32x4 *>(tw + S_H1 + 2 * SLOT_B) = t.xs.l;
+            } else {
+                *reinterpret_cast<u32x4 *>(tw + S_H1) = t.xh;
+                *reinterpret_cast<u32x4 *>(tw + S_H1 + SLOT_B) = t.xl;
+            }
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         char *h1_b = ser_b + 4 * (H1_W + TILE_W * buf);
         *reinterpret_cast<f32x4 *>(h1_b + wr32) = t.ha;
         *reinterpret_cast<f32x4 *>(h1_b + wr32 + 64) = t.hb;
@@ -1314,8 +1405,11 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     // Scratch: the gz tile buffer 0, which is dead between the pairs (LDS operations of a wave run in order).
     auto pa_stage = [&](float y, int p, int64_t t0_cur) -> float {
         const int c = g & 1, tl = 16 * (g >> 1) + j;
-        float *const fbuf = ser + GZ_W;          // [6 taps][32 samples] float2: u P_m(p)
-        float *const gbuf = ser + GZ_W + 384;    // [4 zeros | 28 G | 5 zeros] float2
+        // (OB: the h1 terms of tile A are parked at the start of buffer 0 by now; its gz2 slots are still free)
+        constexpr int PA_SCR = GZ_W + (OB ? S_G2 / 4 : 0);
+        static_assert(PA_SCR + 384 + 74 <= GZ_W + TB_WORDS, "chain scratch inside tile buffer 0");
+        float *const fbuf = ser + PA_SCR;        // [6 taps][32 samples] float2: u P_m(p)
+        float *const gbuf = ser + PA_SCR + 384;  // [4 zeros | 28 G | 5 zeros] float2
         const float o = QAT ? fq16(y, s3) : y;   // straight-through: the gradient passes the quantiser unchanged
         const unsigned ob = __builtin_bit_cast(unsigned, o);
         const auto sw = __builtin_amdgcn_permlane16_swap(ob, ob, false, false);   // (component 0, component 1) in every lane
@@ -1426,11 +1520,32 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         db2 = add4<!BF>(db2, B.gz2);
     };
     auto V4 = [&](Tile &t, int buf) {
+        if constexpr (OB) {             // the terms of gz2, the right factor of dW2: [h|m] in one slot, l in half of the next
+            char *tw = ser_b + 4 * (GZ_W + TB_WORDS * buf) + tw_off;
+            unsigned (&h)[2] = t.g2h, (&m)[2] = t.g2m, (&l)[2] = t.g2l;
+            split_pair3(t.gz2[0], t.gz2[1], h[0], m[0], l[0]);
+            split_pair3(t.gz2[2], t.gz2[3], h[1], m[1], l[1]);
+            *reinterpret_cast<u32x4 *>(tw + S_G2) = u32x4{h[0], h[1], m[0], m[1]};
+            *reinterpret_cast<u32x2 *>(tw + S_G2 + SLOT_B) = u32x2{l[0], l[1]};
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         *reinterpret_cast<f32x4 *>(ser_b + 4 * (GZ_W + TILE_W * buf) + wr32 + 128) = t.gz2;
     };
     auto S5 = [&](Tile &t) {   // gh1^T = W2^T gz2^T  (two row tiles of 16 h1-neurons)
         t.e0 = f32x4{0.f, 0.f, 0.f, 0.f};
         t.e1 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (OB) {        // three K = 32 instructions per row tile: [h|l] x [l|h], [h|m] x [m|h], [h|m] x [h|m]
+            const u32x4 b_lh = {t.g2l[0], t.g2l[1], t.g2h[0], t.g2h[1]}, b_mh = {t.g2m[0], t.g2m[1], t.g2h[0], t.g2h[1]};
+            const u32x4 b_hm = {t.g2h[0], t.g2h[1], t.g2m[0], t.g2m[1]};
+            t.e0 = mfma_bf(T2[0], b_lh, t.e0);
+            t.e1 = mfma_bf(T2[2], b_lh, t.e1);
+            t.e0 = mfma_bf(T2[1], b_mh, t.e0);
+            t.e1 = mfma_bf(T2[3], b_mh, t.e1);
+            t.e0 = mfma_bf(T2[1], b_hm, t.e0);
+            t.e1 = mfma_bf(T2[3], b_hm, t.e1);
+            return;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             t.e0 = mfma4(A2T[0][r], t.gz2[r], t.e0);
@@ -1440,9 +1555,57 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     auto V5 = [&](Tile &t, int buf) {
         t.e0 = mul4<!BF>(t.e0, t.m1a);
         t.e1 = mul4<!BF>(t.e1, t.m1b);
+        if constexpr (OB) {             // the terms of gz1, the right factor of dW1, over the slots of h1 (dW2 has read them)
+            char *tw = ser_b + 4 * (GZ_W + TB_WORDS * buf) + tw_off;
+            Split3 sp;
+            split8(sp, t.e0, t.e1);
+            *reinterpret_cast<u32x4 *>(tw + S_G1) = sp.h;
+            *reinterpret_cast<u32x4 *>(tw + S_G1 + SLOT_B) = sp.m;
+            *reinterpret_cast<u32x4 *>(tw + S_G1 + 2 * SLOT_B) = sp.l;
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
         char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
         *reinterpret_cast<f32x4 *>(gz_b + wr32) = t.e0;
         *reinterpret_cast<f32x4 *>(gz_b + wr32 + 64) = t.e1;
+    };
+    // OB: dW2 += h1 (x) gz2 of one tile
+    auto S6b = [&](int buf) {
+        lds_char *tr = (lds_char *)(ser_b + 4 * (GZ_W + TB_WORDS * buf) + tr_off);
+        OpR g2;
+        read_op(g2, tr, S_G2, S_G2 + 8, S_G2 + SLOT_B);
+        OpL h1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) read_op(h1[u], tr, S_H1 + 8 * u, S_H1 + SLOT_B + 8 * u, SP3 ? S_H1 + 2 * SLOT_B + 8 * u : -1);
+        __builtin_amdgcn_wave_barrier();
+        dW2[0] = outer3(dW2[0], h1[0], g2);
+        dW2[1] = outer3(dW2[1], h1[1], g2);
+    };
+    // OB: dW1 += x (x) gz1 of one tile; the x operand comes straight from the words of the series
+    auto S6a = [&](int toff, int buf) {
+        lds_char *tr = (lds_char *)(ser_b + 4 * (GZ_W + TB_WORDS * buf) + tr_off);
+        OpR g1[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) read_op(g1[t], tr, S_G1 + 8 * t, S_G1 + SLOT_B + 8 * t, S_G1 + 2 * SLOT_B + 8 * t);
+        OpL x[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            unsigned a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = *reinterpret_cast<const unsigned *>(ser_b + xa[u] + toff + 4 * i);
+                if (SP3) b[i] = *reinterpret_cast<const unsigned *>(ser_b + xb[u] + toff + 4 * i);
+            }
+            const unsigned h01 = __builtin_amdgcn_perm(a[1], a[0], 0x07060302u), h23 = __builtin_amdgcn_perm(a[3], a[2], 0x07060302u);
+            x[u].hm = u32x4{h01, h23, __builtin_amdgcn_perm(a[1], a[0], 0x05040100u), __builtin_amdgcn_perm(a[3], a[2], 0x05040100u)};
+            if (SP3) x[u].hl = u32x4{h01, h23, __builtin_amdgcn_perm(b[1], b[0], 0x07060302u), __builtin_amdgcn_perm(b[3], b[2], 0x07060302u)};
+            else x[u].hl = u32x4{h01, h23, 0u, 0u};
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dW1[u][t] = outer3(dW1[u][t], x[u], g1[t]);
     };
     auto S6 = [&](int toff, int buf) {   // samples move from lanes to the MFMA K axis through the LDS tiles
         const char *gz_b = ser_b + 4 * (GZ_W + TILE_W * buf);
@@ -1547,7 +1710,10 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         { unsigned long long now = __builtin_readcyclecounter(); tacc[17] += now - tlast; tlast = now; }
 #endif
-        if constexpr (DIG) commit_series_digits(ser, ser + DSER_W, pre, lane, s0);
+        if constexpr (OB) {
+            commit_point<QAT, DIG, SP3>(ser, pre.p[0], lane, s0);
+            if (lane < 5) commit_point<QAT, DIG, SP3>(ser, pre.p[1], 64 + lane, s0);
+        } else if constexpr (DIG) commit_series_digits(ser, ser + DSER_W, pre, lane, s0);
         else if constexpr (SP3) commit_series_split(ser, ser + DSER_W, ser + DSER_W + SPB_BWD, pre, lane);
         else commit_series<QAT>(ser, pre, lane, s0);
         tg_lds[lane] = pre_tg;
@@ -1607,14 +1773,29 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             S5(A);
             V4(B, 1);
             PHASE();
-            S5(B);
-            V5(A, 0);
-            PHASE();
-            S6(cA, 0);
-            V5(B, 1);
-            PHASE();
-            S6(cB, 1);
-            PHASE();
+            if constexpr (OB) {
+                // h1 and gz1 of a tile share their slots: dW2 reads h1 before the gz1 terms are parked over it
+                S5(B);
+                S6b(0);
+                PHASE();
+                S6b(1);
+                V5(A, 0);
+                PHASE();
+                S6a(cA, 0);
+                V5(B, 1);
+                PHASE();
+                S6a(cB, 1);
+                PHASE();
+            } else {
+                S5(B);
+                V5(A, 0);
+                PHASE();
+                S6(cA, 0);
+                V5(B, 1);
+                PHASE();
+                S6(cB, 1);
+                PHASE();
+            }
         }
     }
 #undef PHASE

@@ -58,11 +58,12 @@ Q88_MFMA_PER_CHUNK = 40
 # 32 cycles during which the SIMD issues nothing else)
 GEN_QAT_FWD_P4 = {"valu": 583, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,3,0>: last abs-max pass
 GEN_QAT_FWD_PA = {"valu": 628, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,4,3>: fused chain forward
-GEN_QAT_BWD = {"valu": 786, "bf16": 48, "fp32": 128}        # k_gen_bwd_mfma<true,true,false>: Stage-1 step
-GEN_QAT_BWD_PA = {"valu": 998, "bf16": 48, "fp32": 128}     # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
-# float generator: FC1 and FC2 of the forward as three-way split bf16 products (18 MFMAs per tile), backward on the fp32 MFMA
+GEN_QAT_BWD = {"valu": 1197, "bf16": 144, "fp32": 0}           # k_gen_bwd_mfma<true,true,false>: Stage-1 step
+GEN_QAT_BWD_PA = {"valu": 1412, "bf16": 144, "fp32": 0}        # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
+# float generator: FC1 and FC2 of the forward as three-way split bf16 products (18 MFMAs per tile); backward products
+# (W2^T, dW1, dW2) as three-way split products as well (24 per tile)
 GEN_FLOAT_FWD_PA = {"valu": 564, "bf16": 72, "fp32": 0}     # k_gen_fwd_mfma<false,4,3>: fused chain forward
-GEN_FLOAT_BWD = {"valu": 700, "bf16": 72, "fp32": 128}      # k_gen_bwd_mfma<false,true,false>
+GEN_FLOAT_BWD = {"valu": 1135, "bf16": 168, "fp32": 0}         # k_gen_bwd_mfma<false,true,false>
 CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + CRITIC_BWD_BF16_MFMA * 16
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
@@ -251,20 +252,24 @@ def run_stage1(ctx, args, qat, steps, warmup):
     k = kt.avg_seconds()
     n = ctx.rows * (ctx.seq - 5)
     flop = 2.0 * (GEN_FWD_MAC + GEN_BWD_MAC) * n
-    matrix, issue, cyc = simd_time_fracs(GEN_QAT_BWD if qat else GEN_FLOAT_BWD, n / 64.0, k)
-    roof = {"bound": "mfma",
-            "kernel": ("k_gen_bwd_mfma<true,true,false>: tap assembly + forward (FC1, FC2 as exact digit products on the bf16 MFMA) + MSE + "
-                       "backward (fp32 MFMA) (+ slab reduce)" if qat else
-                       "k_gen_bwd_mfma<false,true,false>: tap assembly + forward (FC1, FC2 as three-way split products on the bf16 MFMA, "
-                       "fp32 accuracy) + MSE + backward (fp32 MFMA) (+ slab reduce)"),
-            # utilisation of the matrix pipes: cycles the kernel's MFMAs occupy them over the measured kernel cycles; `achieved`
-            # = frac x the fp32 MFMA peak (the pipe that carries the bulk of those cycles)
-            "achieved": matrix * FP32_PEAK_TFLOPS, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": matrix,
-            "frac_definition": "matrix-pipe utilisation: MFMA cycles of one launch (fp32 16x16x4 at 32 cycles, bf16 16x16x32 at 16, "
-                               "counted in the kernel's assembly) / measured kernel cycles per SIMD",
-            "issue_frac": issue, "cycles_per_64_samples": cyc,
-            # algorithmic fp32 flops (2 x (1,504 + 2,048) MAC per sample) over the kernel time against the fp32 peak: not a
-            # utilisation (the forward products run on the bf16 pipe)
+    counts = GEN_QAT_BWD if qat else GEN_FLOAT_BWD
+    matrix, issue, cyc = simd_time_fracs(counts, n / 64.0, k)
+    ginst = (counts["valu"] + counts["bf16"]) * (n / 64.0) / k / 1e9
+    roof = {"bound": "valu-issue",
+            "kernel": ("k_gen_bwd_mfma<true,true,false>: tap assembly + forward (exact digit products) + MSE + backward (three-way split "
+                       "products), all on the bf16 MFMA at fp32 accuracy (+ slab reduce)" if qat else
+                       "k_gen_bwd_mfma<false,true,false>: tap assembly + forward + MSE + backward, every product a three-way split product "
+                       "on the bf16 MFMA at fp32 accuracy (+ slab reduce)"),
+            # The kernel's products run on the bf16 matrix cores (36-42 MFMAs of 16 cycles per tile), which leaves the matrix pipe
+            # mostly idle by design; what bounds it is the issue port of the SIMDs (splits, quantisers, masks, FC3, tanh).  frac =
+            # cycles its vector instructions hold that port over the measured kernel cycles
+            "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s", "frac": issue,
+            "frac_definition": "vector issue time of one launch (%d VALU + %d bf16 MFMA wave-instructions per 64 samples, counted in the "
+                               "kernel's assembly, 4 cycles each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time"
+                               % (counts["valu"], counts["bf16"]),
+            "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
+            # algorithmic fp32 flops (2 x (1,504 + 2,048) MAC per sample) over the kernel time against the fp32 peak: a speed-up
+            # measure, not a utilisation (nothing here runs on the fp32 pipe)
             "fp32_equivalent": {"achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "ratio": flop / k / 1e12 / FP32_PEAK_TFLOPS},
             "traffic": pmc_bytes("k_gen_bwd_mfma<%s,true,false>" % ("true" if qat else "false")) if default_shape(ctx) else None,
@@ -557,12 +562,14 @@ def run_gen_pa_train(ctx, args, steps, warmup):
     # outputs take 19 chunks
     chunks = ctx.rows * float(-(-(ctx.seq - 9) // 56))
     matrix, issue, cyc = simd_time_fracs(GEN_QAT_BWD_PA, chunks, k)
-    roof = {"bound": "mfma", "kernel": "k_gen_bwd_mfma<true,true,true>: tap assembly + generator (FC1, FC2 as exact digit products on the bf16 MFMA) + "
-                                       "quantiser + PA twin + MSE + PA adjoint + generator backward (fp32 MFMA)",
-            "achieved": matrix * FP32_PEAK_TFLOPS, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": matrix,
-            "frac_definition": "matrix-pipe utilisation: MFMA cycles of one launch (128 fp32 16x16x4 at 32 cycles + 48 bf16 16x16x32 at 16 per "
-                               "chunk of 56 PA outputs) / measured kernel cycles per SIMD",
-            "issue_frac": issue, "cycles_per_chunk": cyc,
+    ginst = (GEN_QAT_BWD_PA["valu"] + GEN_QAT_BWD_PA["bf16"]) * chunks / k / 1e9
+    roof = {"bound": "valu-issue",
+            "kernel": "k_gen_bwd_mfma<true,true,true>: tap assembly + generator + quantiser + PA twin + MSE + PA adjoint + generator backward; "
+                      "every matrix product on the bf16 MFMA at fp32 accuracy (digit products forward, three-way split products backward)",
+            "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s", "frac": issue,
+            "frac_definition": "vector issue time of one launch (1,412 VALU + 144 bf16 MFMA wave-instructions per chunk of 56 PA outputs, "
+                               "4 cycles each on the SIMD's issue port) / measured kernel time",
+            "matrix_pipe_frac": matrix, "cycles_per_chunk": cyc,
             "fp32_equivalent": {"achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                 "ratio": flop / k / 1e12 / FP32_PEAK_TFLOPS},
             "traffic": pmc_bytes("k_gen_bwd_mfma<true,true,true>") if default_shape(ctx) else None,
@@ -789,11 +796,13 @@ LABELS = {
     "spectral": "SpectralLoss forward + backward",
 }
 EXTRAS = ("stage1", "stage1_qat", "q88", "q88_stream", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral")
-_QAT_DT = "f32 (QAT generator forward products: exact 2-digit bf16 products of the 16-bit quantised integers, fp32 accumulate)"
-_F32_DT = "f32 (generator forward products: bf16 x 3-way split, fp32 accumulate)"
+_QAT_DT = ("f32 (QAT generator forward products: exact 2-digit bf16 products of the 16-bit quantised integers; backward products: "
+           "bf16 x 3-way split; fp32 accumulate)")
+_F32_DT = "f32 (generator products: bf16 x 3-way split, fp32 accumulate)"
 DTYPE = {"q88": "int16", "q88_stream": "int16",
          "stage2": "f32 (critic hidden-layer products and inner weight gradients: bf16 x 3-way split, fp32 accumulate; QAT generator "
-                   "forward products: exact 2-digit bf16 products of the 16-bit quantised integers, fp32 accumulate)",
+                   "forward products: exact 2-digit bf16 products of the 16-bit quantised integers, its backward products bf16 x 3-way "
+                   "split; fp32 accumulate)",
          "stage1": _F32_DT, "gen_pa_float": _F32_DT, "stage1_qat": _QAT_DT, "gen_pa": _QAT_DT, "gen_pa_train": _QAT_DT}
 
 
