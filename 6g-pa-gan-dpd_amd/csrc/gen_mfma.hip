@@ -560,17 +560,21 @@ struct OpR { u32x4 hm, mh, lh; };           // right factor (columns): [h|m], [m
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 DEV u32x2 tr_read(lds_char *p) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4 *)p)); }
 DEV u32x4 cat(u32x2 a, u32x2 b) { return u32x4{a[0], a[1], b[0], b[1]}; }
-// h, m, l: byte offsets of the 8-byte pieces of the three terms (l < 0: the factor has two terms only)
-DEV void read_op(OpL &o, lds_char *tr, int h, int m, int l) {
-    const u32x2 ph = tr_read(tr + h);
-    o.hm = cat(ph, tr_read(tr + m));
-    o.hl = l >= 0 ? cat(ph, tr_read(tr + l)) : u32x4{ph[0], ph[1], 0u, 0u};
+// h, m, l: byte offsets of the 8-byte pieces of the three terms (l < 0: the factor has two terms only).  tr[0..2] hold
+// the same address, the copies opaque to the compiler: a term that goes into several operands is read once per
+// operand -- merged into one read, the value would have to be copied into place with VALU moves, and an LDS read is
+// the cheaper instruction here.
+struct TrAddr {
+    lds_char *p[3];
+};
+DEV void read_op(OpL &o, const TrAddr &tr, int off, int h, int m, int l) {
+    o.hm = cat(tr_read(tr.p[0] + off + h), tr_read(tr.p[0] + off + m));
+    o.hl = l >= 0 ? cat(tr_read(tr.p[1] + off + h), tr_read(tr.p[0] + off + l)) : cat(tr_read(tr.p[1] + off + h), u32x2{0u, 0u});
 }
-DEV void read_op(OpR &o, lds_char *tr, int h, int m, int l) {
-    const u32x2 ph = tr_read(tr + h), pm = tr_read(tr + m);
-    o.hm = cat(ph, pm);
-    o.mh = cat(pm, ph);
-    o.lh = cat(tr_read(tr + l), ph);
+DEV void read_op(OpR &o, const TrAddr &tr, int off, int h, int m, int l) {
+    o.hm = cat(tr_read(tr.p[0] + off + h), tr_read(tr.p[0] + off + m));
+    o.mh = cat(tr_read(tr.p[1] + off + m), tr_read(tr.p[1] + off + h));
+    o.lh = cat(tr_read(tr.p[0] + off + l), tr_read(tr.p[2] + off + h));
 }
 DEV f32x4 outer3(f32x4 acc, const OpL &a, const OpR &b) {
     acc = mfma_bf(a.hl, b.lh, acc);
@@ -1235,6 +1239,12 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     const int tw_off = 64 * j + 16 * (g ^ ((j >> 1) & 3));
     const int tr_row = 4 * g + (j >> 2);
     const int tr_off = 64 * tr_row + 16 * ((j & 3) ^ ((tr_row >> 1) & 3));
+    TrAddr tra;       // tile buffer 0; buffer 1 is an immediate offset
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        tra.p[k] = (lds_char *)(reinterpret_cast<char *>(ser) + 4 * GZ_W + tr_off);
+        asm volatile("" : "+v"(tra.p[k]));      // (volatile: identical plain asm statements on one input are one value to the optimiser)
+    }
     // dW1 A operand: lane (i = j, g) reads slot 16u + i of sample 4q + g
     int aoff[2];
 #pragma unroll
@@ -1571,22 +1581,22 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
     };
     // OB: dW2 += h1 (x) gz2 of one tile
     auto S6b = [&](int buf) {
-        lds_char *tr = (lds_char *)(ser_b + 4 * (GZ_W + TB_WORDS * buf) + tr_off);
+        const int tb = 4 * TB_WORDS * buf;
         OpR g2;
-        read_op(g2, tr, S_G2, S_G2 + 8, S_G2 + SLOT_B);
+        read_op(g2, tra, tb, S_G2, S_G2 + 8, S_G2 + SLOT_B);
         OpL h1[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) read_op(h1[u], tr, S_H1 + 8 * u, S_H1 + SLOT_B + 8 * u, SP3 ? S_H1 + 2 * SLOT_B + 8 * u : -1);
+        for (int u = 0; u < 2; ++u) read_op(h1[u], tra, tb, S_H1 + 8 * u, S_H1 + SLOT_B + 8 * u, SP3 ? S_H1 + 2 * SLOT_B + 8 * u : -1);
         __builtin_amdgcn_wave_barrier();
         dW2[0] = outer3(dW2[0], h1[0], g2);
         dW2[1] = outer3(dW2[1], h1[1], g2);
     };
     // OB: dW1 += x (x) gz1 of one tile; the x operand comes straight from the words of the series
     auto S6a = [&](int toff, int buf) {
-        lds_char *tr = (lds_char *)(ser_b + 4 * (GZ_W + TB_WORDS * buf) + tr_off);
+        const int tb = 4 * TB_WORDS * buf;
         OpR g1[2];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) read_op(g1[t], tr, S_G1 + 8 * t, S_G1 + SLOT_B + 8 * t, S_G1 + 2 * SLOT_B + 8 * t);
+        for (int t = 0; t < 2; ++t) read_op(g1[t], tra, tb, S_G1 + 8 * t, S_G1 + SLOT_B + 8 * t, S_G1 + 2 * SLOT_B + 8 * t);
         OpL x[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
@@ -1649,6 +1659,17 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
 #define PHASE() __builtin_amdgcn_sched_barrier(0)
 #endif
 
+    // experiment switch: the VALU stage of a phase spread between its bf16 MFMAs (as in the forward kernel)
+#ifndef GEN_BWD_MIX
+#define GEN_BWD_MIX 0
+#endif
+#define BMIX(NM, NV)                                                 \
+    if constexpr (OB && GEN_BWD_MIX) {                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < (NM); ++i_) {        \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       \
+            __builtin_amdgcn_sched_group_barrier(0x002, (NV), 0);    \
+        }                                                            \
+    }
     // The HBM reads of a chunk (69 IQ points, 64 targets or upstream gradients) are issued one chunk
     // ahead and parked in LDS at the top of the next iteration: no load latency inside the tile code.
     const float2 *gsrc = MSE ? target : grad_out;
@@ -1759,9 +1780,11 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
             PHASE();
             S1(B.a0, B.a1, bB);
             V1(A, 0);
+            BMIX(SP3 ? 12 : 8, SP3 ? 5 : 8)
             PHASE();
             S2(A);
             V1(B, 1);
+            BMIX(SP3 ? 6 : 4, SP3 ? 10 : 16)
             PHASE();
             S2(B);
             V2(A);
@@ -1780,9 +1803,11 @@ __global__ __launch_bounds__(WAVES * 64, BWD_WAVES_PER_SIMD) void k_gen_bwd_mfma
                 PHASE();
                 S6b(1);
                 V5(A, 0);
+                BMIX(6, 8)
                 PHASE();
                 S6a(cA, 0);
                 V5(B, 1);
+                BMIX(12, 4)
                 PHASE();
                 S6a(cB, 1);
                 PHASE();
