@@ -296,6 +296,12 @@ struct B3 {            // eight values per lane, split three ways
 };
 DEV void load_b3(B3 &o, const float *img, int q, int lane) {
     o.h = bquad(img, q, lane);
+#ifdef ABL_ONE_TERM_READ      // experiment (timing only, results are wrong): one of the three operand reads
+    o.m = o.h;
+    o.l = o.h;
+    asm volatile("" : "+v"(o.m), "+v"(o.l));
+    return;
+#endif
     o.m = bquad(img, q + 1, lane);
     o.l = bquad(img, q + 2, lane);
 }
