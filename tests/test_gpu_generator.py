@@ -1,6 +1,8 @@
 """GPU parity of the generator path (tap assembly, float and QAT forward/backward) against the
 golden fixtures and the CPU oracle.  Tolerances: tap indexing bit-exact; fp32 outputs rel <= 1e-5
 (atol 1e-6 for values near zero); fake-quantised outputs within one 16-bit step."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -311,3 +313,35 @@ def test_running_scales_in_one_launch_match_the_module_arithmetic():
     gen2.observe_all(absmax)
     gen.observe_all(absmax)
     assert torch.equal(gen2.fc3_weight_quant.running_scale, gen.fc3_weight_quant.running_scale)
+
+
+def test_mfma_generator_accuracy_against_fp64(dpd):
+    """The MFMA family of the float generator runs every matrix product as six bf16 products of three-way split
+    operands (fp32 accumulate).  Output and parameter gradients must stay at fp32 rounding level against an fp64
+    evaluation, next to the VALU family's plain fp32 FMAs (measured, of the largest magnitude, VALU / MFMA: output
+    3.4e-7 / 3.1e-7; gradients 5e-8 / 3.1e-7 -- the MFMA family keeps a wave's gradient sums over thousands of samples
+    in fp32 accumulators, the VALU family hands shorter partial sums to the fp64 reduction; the bounds leave a factor of
+    about 4)."""
+    from oracle import generator as og
+    from dpd_amd.data import ofdm_rows
+    from dpd_amd.models import TDNNGenerator
+    torch.manual_seed(11)
+    iq = ofdm_rows(64, 1029, seed=21, device=DEV)
+    target = (iq[:, 5:, :] * 0.8).contiguous()
+    gen = TDNNGenerator().to(DEV)
+    p64 = {k: v.detach().double().cpu() for k, v in gen.state_dict().items() if k in og.PARAM_KEYS}
+    out64, _, g64 = og.gen_mse_grads(iq.double().cpu(), target.double().cpu(), p64)
+    errs = {}
+    for impl in (1, 2):
+        gen.kernel_impl = impl
+        gen.zero_grad()
+        out = gen(iq)
+        torch.nn.functional.mse_loss(out, target).backward()
+        e_out = float((out.detach().double().cpu() - out64).abs().max() / out64.abs().max())
+        e_g = max(float((dict(gen.named_parameters())[k].grad.double().cpu() - g64[k]).abs().max() / g64[k].abs().max())
+                  for k in og.PARAM_KEYS)
+        errs[impl] = (e_out, e_g)
+    if os.environ.get("DPD_CLOSE_REPORT"):
+        print("generator error against fp64 (output, gradients): VALU %.2e %.2e, MFMA %.2e %.2e" % (errs[1] + errs[2]))
+    assert errs[2][0] < 1.2e-6 and errs[2][1] < 1.2e-6
+    assert errs[2][0] < 2 * errs[1][0] + 1e-7
