@@ -49,21 +49,23 @@ PA_BWD_FLOP = 400
 # the first-layer weight gradient on v_mfma_f32_4x4x1_16b_f32 (16 x 8); the hidden-layer products (60) and the weight
 # gradients of the two inner layers (30) as three-way-split bf16 operands on v_mfma_f32_16x16x32_bf16 (16 cycles)
 CRITIC_BWD_BF16_MFMA = 90
-# k_q88_mfma, per chunk of 64 samples and wave, counted in the chunk loop of the compiled kernel (scratch/isa_hist.py)
-Q88_VALU_PER_CHUNK = 633
+# k_q88_mfma, per chunk of 64 samples and wave: executed instructions, (SQ_INSTS_VALU - SQ_INSTS_MFMA) / chunks of a counter
+# pass over the workload (profiles/r3_pmc_extras.json; the chunk loop of the compiled kernel holds 633 with its rarely taken branches)
+Q88_VALU_PER_CHUNK = 573
 Q88_MFMA_PER_CHUNK = 40
 # QAT generator kernels in the digit form (fake-quantised values as two exact bf16 digits), per chunk of 64 samples and
-# wave, counted in the loop bodies of the compiled kernels (scratch/isa_hist.py): vector-ALU instructions, bf16 MFMAs
+# wave, executed instructions from the counter passes in profiles/r3_pmc_extras.json ((SQ_INSTS_VALU - SQ_INSTS_MFMA) / chunks;
+# the loop bodies of the compiled kernels, scratch/isa_hist.py, hold 7-10 % more in rarely taken branches): vector-ALU instructions, bf16 MFMAs
 # (v_mfma_f32_16x16x32_bf16, 16 cycles on the matrix pipe, 4 on the issue port) and fp32 MFMAs (v_mfma_f32_16x16x4_f32,
 # 32 cycles during which the SIMD issues nothing else)
-GEN_QAT_FWD_P4 = {"valu": 583, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,3,0>: last abs-max pass
-GEN_QAT_FWD_PA = {"valu": 628, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,4,3>: fused chain forward
-GEN_QAT_BWD = {"valu": 1197, "bf16": 144, "fp32": 0}           # k_gen_bwd_mfma<true,true,false>: Stage-1 step
-GEN_QAT_BWD_PA = {"valu": 1412, "bf16": 144, "fp32": 0}        # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
+GEN_QAT_FWD_P4 = {"valu": 542, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,3,0>: last abs-max pass
+GEN_QAT_FWD_PA = {"valu": 587, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,4,3>: fused chain forward
+GEN_QAT_BWD = {"valu": 1115, "bf16": 144, "fp32": 0}           # k_gen_bwd_mfma<true,true,false>: Stage-1 step
+GEN_QAT_BWD_PA = {"valu": 1299, "bf16": 140, "fp32": 0}        # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
 # float generator: FC1 and FC2 of the forward as three-way split bf16 products (18 MFMAs per tile); backward products
 # (W2^T, dW1, dW2) as three-way split products as well (24 per tile)
-GEN_FLOAT_FWD_PA = {"valu": 564, "bf16": 72, "fp32": 0}     # k_gen_fwd_mfma<false,4,3>: fused chain forward
-GEN_FLOAT_BWD = {"valu": 1135, "bf16": 168, "fp32": 0}         # k_gen_bwd_mfma<false,true,false>
+GEN_FLOAT_FWD_PA = {"valu": 517, "bf16": 72, "fp32": 0}     # k_gen_fwd_mfma<false,4,3>: fused chain forward
+GEN_FLOAT_BWD = {"valu": 1048, "bf16": 168, "fp32": 0}         # k_gen_bwd_mfma<false,true,false>
 CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + CRITIC_BWD_BF16_MFMA * 16
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
@@ -264,8 +266,8 @@ def run_stage1(ctx, args, qat, steps, warmup):
             # mostly idle by design; what bounds it is the issue port of the SIMDs (splits, quantisers, masks, FC3, tanh).  frac =
             # cycles its vector instructions hold that port over the measured kernel cycles
             "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s", "frac": issue,
-            "frac_definition": "vector issue time of one launch (%d VALU + %d bf16 MFMA wave-instructions per 64 samples, counted in the "
-                               "kernel's assembly, 4 cycles each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time"
+            "frac_definition": "vector issue time of one launch (%d VALU + %d bf16 MFMA wave-instructions per 64 samples, executed counts "
+                               "from a counter pass, 4 cycles each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time"
                                % (counts["valu"], counts["bf16"]),
             "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
             # algorithmic fp32 flops (2 x (1,504 + 2,048) MAC per sample) over the kernel time against the fp32 peak: a speed-up
@@ -358,14 +360,14 @@ def q88_roof(ctx, k, eng):
         # Matrix-core form.  What bounds it is the issue port of the SIMDs: per chunk of 64 samples a wave issues
         # Q88_VALU_PER_CHUNK vector-ALU instructions (requantisation, LeakyReLU, digit split, feature planes; counted in the
         # kernel's ISA, scratch/isa_hist.py) and 40 MFMAs.  A wave64 VALU instruction holds the port of its SIMD for 4 cycles,
-        # an int8 MFMA for 4 of its 16: the floor is (633 x 4 + 40 x 4) cycles per chunk and SIMD.  frac = that floor over the
+        # an int8 MFMA for 4 of its 16: the floor is (573 x 4 + 40 x 4) cycles per chunk and SIMD.  frac = that floor over the
         # measured kernel time; the matrix pipe and HBM are reported beside it and are far from their peaks.
         chunks_per_simd = n / 64.0 / N_SIMD
         issue_s = chunks_per_simd * (Q88_VALU_PER_CHUNK * 4 + Q88_MFMA_PER_CHUNK * 4) / CLOCK_HZ
         ginst = (Q88_VALU_PER_CHUNK + Q88_MFMA_PER_CHUNK) * (n / 64.0) / k / 1e9
         peak = N_SIMD * CLOCK_HZ / 4 / 1e9
         return {"bound": "valu-issue", "achieved": ginst, "peak": peak, "unit": "G wave-instructions/s", "frac": issue_s / k,
-                "frac_definition": "vector issue time of one launch (633 VALU + 40 MFMA wave-instructions per 64 samples, 4 cycles each "
+                "frac_definition": "vector issue time of one launch (573 VALU + 40 MFMA wave-instructions per 64 samples, 4 cycles each "
                                    "on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
                 "kernel": "k_q88_mfma (v_mfma_i32_16x16x64_i8, int16 = two 8-bit digits, three int32 accumulators per product)",
                 "issue_floor_ms": issue_s * 1e3, "kernel_ms": k * 1e3, "valu_per_64_samples": Q88_VALU_PER_CHUNK,
@@ -476,7 +478,7 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         ginst = (GEN_FLOAT_FWD_PA["valu"] + GEN_FLOAT_FWD_PA["bf16"]) * (n / 64.0) / k / 1e9
         roof.update({"bound": "valu-issue", "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s",
                      "frac": issue,
-                     "frac_definition": "vector issue time of one launch (564 VALU + 72 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
+                     "frac_definition": "vector issue time of one launch (517 VALU + 72 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
                                         "each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
                      "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
                      "fp32_equivalent": {"achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -491,7 +493,7 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         ginst = (GEN_QAT_FWD_P4["valu"] + GEN_QAT_FWD_P4["bf16"]) * (n / 64.0) / k / 1e9
         roof.update({"bound": "valu-issue", "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s",
                      "frac": issue,
-                     "frac_definition": "vector issue time of one launch (583 VALU + 48 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
+                     "frac_definition": "vector issue time of one launch (542 VALU + 48 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
                                         "each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
                      "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
                      "fp32_equivalent": {"achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -528,7 +530,7 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         fmatrix, fissue, fcyc = simd_time_fracs(GEN_QAT_FWD_PA, n / 64.0, kf)
         roof["fused_qat_kernel"] = {"kernel": "k_gen_fwd_mfma<true,4,3>: tap assembly + QAT generator (quantisers on chip, scales given) + PA twin in one kernel",
                                     "kernel_ms": kf * 1e3, "bound": "valu-issue", "frac": fissue,
-                                    "frac_definition": "as above with 628 VALU + 48 bf16 MFMA wave-instructions per 64 samples",
+                                    "frac_definition": "as above with 587 VALU + 48 bf16 MFMA wave-instructions per 64 samples",
                                     "matrix_pipe_frac": fmatrix, "cycles_per_64_samples": fcyc,
                                     "fp32_equivalent": {"achieved": flop / kf / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                         "ratio": flop / kf / 1e12 / FP32_PEAK_TFLOPS},
@@ -567,7 +569,7 @@ def run_gen_pa_train(ctx, args, steps, warmup):
             "kernel": "k_gen_bwd_mfma<true,true,true>: tap assembly + generator + quantiser + PA twin + MSE + PA adjoint + generator backward; "
                       "every matrix product on the bf16 MFMA at fp32 accuracy (digit products forward, three-way split products backward)",
             "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s", "frac": issue,
-            "frac_definition": "vector issue time of one launch (1,412 VALU + 144 bf16 MFMA wave-instructions per chunk of 56 PA outputs, "
+            "frac_definition": "vector issue time of one launch (1,299 VALU + 140 bf16 MFMA wave-instructions per chunk of 56 PA outputs, "
                                "4 cycles each on the SIMD's issue port) / measured kernel time",
             "matrix_pipe_frac": matrix, "cycles_per_chunk": cyc,
             "fp32_equivalent": {"achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",

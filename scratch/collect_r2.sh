@@ -21,6 +21,7 @@ if [ "$2" = "extras" ]; then
   for W in stage1 stage1_qat q88 gen_pa gen_pa_float gen_pa_train spectral; do
     pass $W fetch FETCH_SIZE || exit 1
     pass $W write WRITE_SIZE || exit 1
+    pass $W sq SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES || exit 1
   done
 fi
 cd $R
