@@ -203,7 +203,7 @@ __global__ __launch_bounds__(TPB) void k_q88(const int *__restrict__ iq, int64_t
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 constexpr int MW = 4;                 // waves per workgroup
 #ifndef Q88_MFMA_WAVES
-#define Q88_MFMA_WAVES 3              // resident waves per SIMD (register budget 168)
+#define Q88_MFMA_WAVES 4              // resident waves per SIMD (register budget 128; measured 3 / 4 / 5: 0.365 / 0.355 / 0.354 ms, 5 spills)
 #endif
 constexpr int PLANE = 96;             // bytes per digit plane: 69 points + the over-read of the last dword, multiple of 4
 constexpr int WAVE_LDS = 10 * PLANE;  // [digit 0..1][series 0..4]
@@ -462,7 +462,10 @@ __global__ __launch_bounds__(MW * 64, Q88_MFMA_WAVES) void k_q88_mfma(const int 
                 requant_act4(hh, xx, ll, p20, p21);
             }
             digits4(p20, p21, x3h[c], x3l[c]);
-            __builtin_amdgcn_sched_barrier(0);     // one tile at a time: keeps the register count down
+#ifdef Q88_TILE_FENCE      // (one tile at a time keeps the register count at 104 instead of 120; without the fence 1 % faster at four
+                           // waves.  Two tiles half a stage apart in one stream, as in the generator kernels: 2-4 % slower.)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
         }
         // ---- FC3 of the whole chunk and the output table: lane (c, j) gets outputs 0, 1 of sample 16 c + j = its own lane index
         {
