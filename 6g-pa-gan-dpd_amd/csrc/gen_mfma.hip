@@ -392,6 +392,9 @@ DEV f32x4 fq16x4(f32x4 v, QS k) {
 #ifndef GEN_QAT_DIGITS
 #define GEN_QAT_DIGITS 1
 #endif
+#ifndef GEN_SPLIT_CVT
+#define GEN_SPLIT_CVT 1      // the last term of a split through v_cvt_pk_bf16_f32 (exact here) instead of a byte permute
+#endif
 #ifdef ABL_NO_MFMA
 DEV f32x4 mfma_bf(u32x4 a, u32x4 b, f32x4 c) { asm volatile("" : "+v"(c) : "v"(a), "v"(b)); return c; }
 #else
@@ -429,7 +432,12 @@ DEV void digit_pair(float q0, float q1, unsigned &hi, unsigned &lo) {
     const unsigned u0 = __builtin_bit_cast(unsigned, q0), u1 = __builtin_bit_cast(unsigned, q1);
     hi = __builtin_amdgcn_perm(u1, u0, 0x07060302u);
     const float l0 = q0 - __builtin_bit_cast(float, u0 & 0xffff0000u), l1 = q1 - __builtin_bit_cast(float, u1 & 0xffff0000u);
+#if GEN_SPLIT_CVT       // (at most 8 significant bits: exact; see split_pair3)
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    lo = __builtin_bit_cast(unsigned, bf16x2{(__bf16)l0, (__bf16)l1});
+#else
     lo = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, l1), __builtin_bit_cast(unsigned, l0), 0x07060302u);
+#endif
 }
 // one float integer -> the word (hi digit << 16 | lo digit) a series holds per point
 DEV float digit_word(float q) {
@@ -455,6 +463,7 @@ DEV float digit_word(float q) {
 #ifndef GEN_SPLIT_PK
 #define GEN_SPLIT_PK 0
 #endif
+
 DEV void split_words(float x, float &a, float &b) {
     const unsigned u = __builtin_bit_cast(unsigned, x);
     const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
@@ -478,7 +487,14 @@ DEV void split_pair3(float x0, float x1, unsigned &h, unsigned &m, unsigned &l) 
     const unsigned v0 = __builtin_bit_cast(unsigned, r0), v1 = __builtin_bit_cast(unsigned, r1);
     m = __builtin_amdgcn_perm(v1, v0, 0x07060302u);
     const float q0 = r0 - __builtin_bit_cast(float, v0 & 0xffff0000u), q1 = r1 - __builtin_bit_cast(float, v1 & 0xffff0000u);
+#if GEN_SPLIT_CVT
+    // (the rest has at most 8 significant bits: the conversion is exact; written this way the compiler pairs the
+    // subtractions above into packed instructions by itself)
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    l = __builtin_bit_cast(unsigned, bf16x2{(__bf16)q0, (__bf16)q1});
+#else
     l = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, q1), __builtin_bit_cast(unsigned, q0), 0x07060302u);
+#endif
 #endif
 }
 struct Split3 {          // eight values per lane as three bf16 operands
