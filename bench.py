@@ -58,14 +58,14 @@ Q88_MFMA_PER_CHUNK = 40
 # the loop bodies of the compiled kernels, scratch/isa_hist.py, hold 7-10 % more in rarely taken branches): vector-ALU instructions, bf16 MFMAs
 # (v_mfma_f32_16x16x32_bf16, 16 cycles on the matrix pipe, 4 on the issue port) and fp32 MFMAs (v_mfma_f32_16x16x4_f32,
 # 32 cycles during which the SIMD issues nothing else)
-GEN_QAT_FWD_P4 = {"valu": 542, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,3,0>: last abs-max pass
-GEN_QAT_FWD_PA = {"valu": 587, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,4,3>: fused chain forward
-GEN_QAT_BWD = {"valu": 1115, "bf16": 144, "fp32": 0}           # k_gen_bwd_mfma<true,true,false>: Stage-1 step
-GEN_QAT_BWD_PA = {"valu": 1299, "bf16": 140, "fp32": 0}        # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
+GEN_QAT_FWD_P4 = {"valu": 526, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,3,0>: last abs-max pass
+GEN_QAT_FWD_PA = {"valu": 571, "bf16": 48, "fp32": 0}       # k_gen_fwd_mfma<true,4,3>: fused chain forward
+GEN_QAT_BWD = {"valu": 1056, "bf16": 144, "fp32": 0}           # k_gen_bwd_mfma<true,true,false>: Stage-1 step
+GEN_QAT_BWD_PA = {"valu": 1231, "bf16": 140, "fp32": 0}        # k_gen_bwd_mfma<true,true,true>: chain step (56 outputs per chunk)
 # float generator: FC1 and FC2 of the forward as three-way split bf16 products (18 MFMAs per tile); backward products
 # (W2^T, dW1, dW2) as three-way split products as well (24 per tile)
-GEN_FLOAT_FWD_PA = {"valu": 517, "bf16": 72, "fp32": 0}     # k_gen_fwd_mfma<false,4,3>: fused chain forward
-GEN_FLOAT_BWD = {"valu": 1048, "bf16": 168, "fp32": 0}         # k_gen_bwd_mfma<false,true,false>
+GEN_FLOAT_FWD_PA = {"valu": 492, "bf16": 72, "fp32": 0}     # k_gen_fwd_mfma<false,4,3>: fused chain forward
+GEN_FLOAT_BWD = {"valu": 980, "bf16": 168, "fp32": 0}         # k_gen_bwd_mfma<false,true,false>
 CRITIC_BWD_MFMA_CYCLES = 4 * 32 + 16 * 8 + CRITIC_BWD_BF16_MFMA * 16
 METRIC = "IQ samples/s: Q8.8 DPD inference + CWGAN-GP train step, 1/2/4/8 MI355X"
 
@@ -478,7 +478,7 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         ginst = (GEN_FLOAT_FWD_PA["valu"] + GEN_FLOAT_FWD_PA["bf16"]) * (n / 64.0) / k / 1e9
         roof.update({"bound": "valu-issue", "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s",
                      "frac": issue,
-                     "frac_definition": "vector issue time of one launch (517 VALU + 72 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
+                     "frac_definition": "vector issue time of one launch (492 VALU + 72 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
                                         "each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
                      "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
                      "fp32_equivalent": {"achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -493,7 +493,7 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         ginst = (GEN_QAT_FWD_P4["valu"] + GEN_QAT_FWD_P4["bf16"]) * (n / 64.0) / k / 1e9
         roof.update({"bound": "valu-issue", "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s",
                      "frac": issue,
-                     "frac_definition": "vector issue time of one launch (542 VALU + 48 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
+                     "frac_definition": "vector issue time of one launch (526 VALU + 48 bf16 MFMA wave-instructions per 64 samples, 4 cycles "
                                         "each on the SIMD's issue port, 1,024 SIMDs at 2.4 GHz) / measured kernel time",
                      "matrix_pipe_frac": matrix, "cycles_per_64_samples": cyc,
                      "fp32_equivalent": {"achieved": kflop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -530,7 +530,7 @@ def run_gen_pa(ctx, args, steps, warmup, qat=True):
         fmatrix, fissue, fcyc = simd_time_fracs(GEN_QAT_FWD_PA, n / 64.0, kf)
         roof["fused_qat_kernel"] = {"kernel": "k_gen_fwd_mfma<true,4,3>: tap assembly + QAT generator (quantisers on chip, scales given) + PA twin in one kernel",
                                     "kernel_ms": kf * 1e3, "bound": "valu-issue", "frac": fissue,
-                                    "frac_definition": "as above with 587 VALU + 48 bf16 MFMA wave-instructions per 64 samples",
+                                    "frac_definition": "as above with 571 VALU + 48 bf16 MFMA wave-instructions per 64 samples",
                                     "matrix_pipe_frac": fmatrix, "cycles_per_64_samples": fcyc,
                                     "fp32_equivalent": {"achieved": flop / kf / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                                         "ratio": flop / kf / 1e12 / FP32_PEAK_TFLOPS},
@@ -569,7 +569,7 @@ def run_gen_pa_train(ctx, args, steps, warmup):
             "kernel": "k_gen_bwd_mfma<true,true,true>: tap assembly + generator + quantiser + PA twin + MSE + PA adjoint + generator backward; "
                       "every matrix product on the bf16 MFMA at fp32 accuracy (digit products forward, three-way split products backward)",
             "achieved": ginst, "peak": N_SIMD * CLOCK_HZ / 4 / 1e9, "unit": "G wave-instructions/s", "frac": issue,
-            "frac_definition": "vector issue time of one launch (1,299 VALU + 140 bf16 MFMA wave-instructions per chunk of 56 PA outputs, "
+            "frac_definition": "vector issue time of one launch (1,231 VALU + 140 bf16 MFMA wave-instructions per chunk of 56 PA outputs, "
                                "4 cycles each on the SIMD's issue port) / measured kernel time",
             "matrix_pipe_frac": matrix, "cycles_per_chunk": cyc,
             "fp32_equivalent": {"achieved": flop / k / 1e12, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
