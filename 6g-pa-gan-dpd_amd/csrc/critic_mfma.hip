@@ -66,7 +66,16 @@ constexpr int QB_A3 = 30;   // [term]         W3[i][16(e >> 2) + 4g + (e & 3)]
 constexpr int QB_A2T = 33;  // [t][term]      W2[16(e >> 2) + 4g + (e & 3)][16t + i]
 constexpr int QB_A3T = 45;  // [u][pair]      W3[4g + (e & 3)][16u + i], term h for e < 4, l (pair 0) or m (pair 1) for e >= 4:
                             //                K = 32 = the 16 layer-3 neurons in two terms (see chain_top)
-constexpr int NQUAD = 49;
+// FC1 on the bf16 matrix cores as well (CRITIC_FC1_BF16): K = 4 inputs, one per lane group, so the eight k-slots of a lane
+// group hold the six products of its input -- weight terms [h, h, m, h, l, m] against input terms [h, m, h, l, h, m] -- and
+// the two spare slots of groups 0 and 1 carry the three terms of the bias against constant ones: one MFMA per 16-row tile
+// with a zero start replaces one fp32 MFMA (32 cycles during which the SIMD issues nothing else) and the bias quad.
+// Measured: weight-gradient pass -0.8 %, input-gradient kernel +5 %, one-pass penalty +2.7 % (four spilled registers): off.
+#ifndef CRITIC_FC1_BF16
+#define CRITIC_FC1_BF16 0
+#endif
+constexpr int QB_A1B = 49;  // [t]            FC1 weights and bias of row 16t + i in the slot order above
+constexpr int NQUAD = CRITIC_FC1_BF16 ? 53 : 49;
 #else
 constexpr int Q_A1 = 0;     // [t]            e = t : W1[16t + i][g]
 constexpr int Q_A2 = 1;     // [u][t]         e = r : W2[16u + i][16t + 4g + r]
@@ -81,7 +90,7 @@ constexpr int Q_B4 = 36;    //                e = 0 : b4, else 0
 constexpr int Q_W4 = 37;    //                e = r : W4[4g + r] (VALU operand)
 constexpr int NQUAD = 38;
 #endif
-constexpr int IMG_WORDS = NQUAD * 64 * 4;          // 9728
+constexpr int IMG_WORDS = NQUAD * 64 * 4;          // 9728 (10752 with the FC1 quads)
 // The weight gradients of the two inner layers (sums over the samples of a tile of h x d) on the bf16 matrix
 // cores as well: the three bf16 terms of both factors exist anyway (the forward and the chain split them), so
 // they are parked in LDS as [sample][neuron] slots and read back with the transposing ds_read_b64_tr_b16,
@@ -148,7 +157,12 @@ DEV void build_image(float *img, const float *__restrict__ wb) {
                 if (q < QB_A3) { int k = q - QB_A2; term = k % 3; int u = k / 6, qq = (k / 3) & 1; x = wb[C_W2 + (16 * u + i) * 64 + 32 * qq + n]; }
                 else if (q < QB_A2T) { term = q - QB_A3; x = wb[C_W3 + i * 32 + n]; }
                 else if (q < QB_A3T) { int k = q - QB_A2T; term = k % 3; int t = k / 3; x = wb[C_W2 + n * 64 + 16 * t + i]; }
-                else { int k = q - QB_A3T; term = e < 4 ? 0 : ((k & 1) ? 1 : 2); x = wb[C_W3 + (4 * g + (e & 3)) * 32 + 16 * (k >> 1) + i]; }
+                else if (q < QB_A1B) { int k = q - QB_A3T; term = e < 4 ? 0 : ((k & 1) ? 1 : 2); x = wb[C_W3 + (4 * g + (e & 3)) * 32 + 16 * (k >> 1) + i]; }
+                else {                                             // FC1: weight terms h, h, m, h, l, m; bias terms in the spare slots
+                    const int t = q - QB_A1B;
+                    if (e < 6) { term = e == 2 || e == 5 ? 1 : (e == 4 ? 2 : 0); x = wb[C_W1 + (16 * t + i) * 4 + g]; }
+                    else { term = g == 0 ? e - 6 : 2; x = (g == 0 || (g == 1 && e == 6)) ? wb[C_B1 + 16 * t + i] : 0.f; }
+                }
                 __bf16 h, m, l;
                 split3(x, h, m, l);
                 v[e] = term == 0 ? h : (term == 1 ? m : l);
@@ -388,8 +402,22 @@ DEV void mfma6x2(f32x4 &lo0, f32x4 &hi0, f32x4 &lo1, f32x4 &hi1, const B3 &a0, c
 
 struct FrontOps {      // FC1 weights and accumulator start (b1), FC2 accumulator start (b2), FC2 weights of the first k-step
     f32x4 a1, b1[4], b2[2];
+    bf16x8 a1b[4];     // CRITIC_FC1_BF16: FC1 weights and bias as one bf16 operand per row tile (a1, b1 unused then)
     B3 w[2];
 };
+// one fp32 value per lane -> the B operand of the FC1 product: terms [h, m, h, l, h, m] and `ones` in the two spare slots
+// (bf16 ones where the A operand carries bias terms: 0x3f803f80 in lane group 0, 0x00003f80 in group 1; 0 for a product
+// without bias)
+DEV bf16x8 fc1_operand(float x, unsigned ones) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const unsigned u = __builtin_bit_cast(unsigned, x);
+    const float r1 = x - __builtin_bit_cast(float, u & 0xffff0000u);
+    const unsigned v = __builtin_bit_cast(unsigned, r1);
+    const float r2 = r1 - __builtin_bit_cast(float, v & 0xffff0000u);
+    const unsigned hm = __builtin_amdgcn_perm(v, u, 0x07060302u), hl = __builtin_amdgcn_perm(__builtin_bit_cast(unsigned, r2), u, 0x07060302u);
+    return __builtin_bit_cast(bf16x8, u32x4{hm, hl, hm, ones});
+}
+DEV unsigned fc1_ones(int lane) { return (lane >> 4) == 0 ? 0x3f803f80u : ((lane >> 4) == 1 ? 0x00003f80u : 0u); }
 struct Fc3Ops {        // FC3 accumulator start (b3) and weights; W4 and b4 for the VALU last layer
     f32x4 b3, w4;
     float b4;          // read with the other operands, one MFMA group ahead: a read at its use would expose the LDS latency
@@ -409,14 +437,20 @@ struct BotOps {        // W2^T, row tiles 0 and 1
 #define CRITIC_RESIDENT 1
 #endif
 DEV void load_resident(FrontOps &o, const float *img, int lane) {
-    o.a1 = quad(img, Q_A1, lane);
+    if (!CRITIC_FC1_BF16) {
+        o.a1 = quad(img, Q_A1, lane);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) o.b1[t] = quad(img, Q_B1 + t, lane);
+        for (int t = 0; t < 4; ++t) o.b1[t] = quad(img, Q_B1 + t, lane);
+    }
     o.b2[0] = quad(img, Q_B2, lane);
     o.b2[1] = quad(img, Q_B2 + 1, lane);
 }
 DEV void load_ops(FrontOps &o, const float *img, int lane) {
     if (!CRITIC_RESIDENT) load_resident(o, img, lane);
+    if (CRITIC_FC1_BF16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o.a1b[t] = bquad(img, QB_A1B + t, lane);
+    }
     load_b3(o.w[0], img, QB_A2, lane);
     load_b3(o.w[1], img, QB_A2 + 6, lane);
 }
@@ -489,8 +523,14 @@ DEV void forward_front(Acts &a, const float *img, int lane, float in, float slop
                        unsigned long long *ts = nullptr, Keep keep = Keep()) {
     a.bits = 0u;
     TS(0)
+    if (CRITIC_FC1_BF16) {
+        const bf16x8 b = fc1_operand(in, fc1_ones(lane));
 #pragma unroll
-    for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, o.b1[t]);
+        for (int t = 0; t < 4; ++t) a.h1[t] = mfma_bf(o.a1b[t], b, f32x4{0.f, 0.f, 0.f, 0.f});
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) a.h1[t] = mfma4(o.a1[t], in, o.b1[t]);
+    }
     TS(1)
     f32x4 z0 = o.b2[0], z1 = o.b2[1];
     fc2_block<true, BITS>(z0, z1, a.h1, o.w, a.m1, a.bits, img, lane, slope, pre, ts, keep);
@@ -1789,7 +1829,9 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_c_mfma(const fl
         const float ghb = g == 0 ? gh0 : (g == 1 ? gh1 : 0.f);
         f32x4 du1[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) du1[t] = mfma4(front.a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f}) * m1[t];
+        for (int t = 0; t < 4; ++t)
+            du1[t] = (CRITIC_FC1_BF16 ? mfma_bf(front.a1b[t], fc1_operand(ghb, 0u), f32x4{0.f, 0.f, 0.f, 0.f})
+                                      : mfma4(front.a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f})) * m1[t];
         // dv2 = W2 du1, du2 = dv2 * D2
         f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
         TopOps top;
@@ -2015,8 +2057,14 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
         B3 sv2;
         chain_top(v3, m2, v2, sv2, top, [&] { load_ops(bot, lds, lane); },
                   [&](const unsigned (&bh)[2], const unsigned (&bm)[2], const unsigned (&bl)[2]) { park_single(ad, S_D3, bh, bm, bl); });
-        chain_bottom(lds, lane, v2, sv2, m1, v1, bot, [&] { load_ops(ino, lds, lane); },
-                     [&](const B3 &b) { park_b3(ad, S_D2, b); });      // after read_p1: inside the p1 tile
+        bf16x8 a1u[4];           // (FC1 operands once more, for the u-chain: kept from the forward they would cost 16 registers)
+        chain_bottom(lds, lane, v2, sv2, m1, v1, bot, [&] {
+            load_ops(ino, lds, lane);
+            if (CRITIC_FC1_BF16) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) a1u[t] = bquad(lds, QB_A1B + t, lane);
+            }
+        }, [&](const B3 &b) { park_b3(ad, S_D2, b); });      // after read_p1: inside the p1 tile
         PRIO_V();
         float g0, g1;
         to_input(v1, g0, g1, ino);
@@ -2029,7 +2077,9 @@ __global__ __launch_bounds__(WG_WAVES * 64, WG_PER_CU) void k_gp_fused_mfma(cons
         const float ghb = g == 0 ? g0 : (g == 1 ? g1 : 0.f);
         f32x4 du1[4];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) du1[t] = mfma4(front.a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f}) * m1[t];
+        for (int t = 0; t < 4; ++t)
+            du1[t] = (CRITIC_FC1_BF16 ? mfma_bf(a1u[t], fc1_operand(ghb, 0u), f32x4{0.f, 0.f, 0.f, 0.f})
+                                      : mfma4(front.a1[t], ghb, f32x4{0.f, 0.f, 0.f, 0.f})) * m1[t];
         f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = {0.f, 0.f, 0.f, 0.f};
         unsigned no_bits = 0u;
         f32x4 unused_m[4];

@@ -335,10 +335,15 @@ def test_mfma_critic_accuracy_against_fp64():
     Wd = [W.double().requires_grad_(True) for W in Ws]
     bd = [b.double().requires_grad_(True) for b in bs]
     h = torch.cat([xd, c.double()], 1)
+    edge = torch.zeros(N, dtype=torch.bool)
     for k in range(4):
         h = h @ Wd[k].T + bd[k]
         if k < 3:
+            # a pre-activation within fp32 rounding of zero (one of 7 * 10^6 here is at 1e-8) takes its LeakyReLU slope
+            # from the last bit of an fp32 sum, whatever evaluates it: such samples get no upstream gradient
+            edge |= (h.detach().abs() < 1e-6).any(1)
             h = torch.nn.functional.leaky_relu(h, 0.2)
+    gs = torch.where(edge, torch.zeros_like(gs), gs)
     score = h[:, 0]
     (score * gs.double()).sum().backward()
     ref_g = torch.cat([t.grad.reshape(-1) for W, b in zip(Wd, bd) for t in (W, b)])
