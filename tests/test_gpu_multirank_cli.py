@@ -85,3 +85,33 @@ def test_train_two_ranks_with_a_row_count_that_does_not_divide(tmp_path):
     epochs = [ln for ln in p.stdout.splitlines() if ln.startswith("epoch ")]
     assert len(epochs) == 2 and "stage 2" in epochs[1], p.stdout[-2000:]
     assert (out / "latest.pth").exists()
+
+
+def test_bench_line_contract_single_gpu():
+    """The one JSON line of a single-GPU run (small rows, extras on, CPU baselines off): the keys the driver reads, the
+    roofline object of the headline and of every extra workload, and a frac that is a fraction."""
+    env = _env()
+    env.pop("DPD_BENCH_REHEARSAL")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--rows", "256", "--stream-chunks", "2",
+           "--no-cpu-baseline"]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=280)
+    assert p.returncode == 0, (p.stdout[-2000:], p.stderr[-4000:])
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    res = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "extra"):
+        assert k in res, k
+    assert res["n_gpus"] == 1 and res["steps"] == 2 and res["warmup"] == 1 and res["scaling"] == "weak"
+    assert res["higher_is_better"] is True and res["vs_baseline"] is None and res["data"] == "synthetic"
+    assert res["unit"] == "samples/s" and "workload" in res["config"]
+    assert abs(res["value"] - 256 * 1024 / (res["ms_per_step"] * 1e-3)) <= 1e-6 * res["value"]
+    roofs = {"stage2": res["roofline"], **{k: v["roofline"] for k, v in res["extra"].items()}}
+    assert set(roofs) == {"stage2", "stage1", "stage1_qat", "q88", "q88_stream", "gen_pa", "gen_pa_float", "gen_pa_train", "spectral"}
+    for name, r in roofs.items():
+        assert r["bound"] in ("hbm", "mfma", "valu-issue"), name
+        assert r["unit"] in ("GB/s", "TFLOP/s", "G wave-instructions/s"), name
+        assert np.isfinite(r["achieved"]) and r["peak"] > 0 and "traffic" in r, name
+        assert 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) <= 1e-6 + 1e-3 * r["frac"], (name, r["frac"])
+    for v in res["extra"].values():
+        assert np.isfinite(v["value"]) and v["value"] > 0 and "dtype" in v
