@@ -58,8 +58,11 @@ static_assert((size_t)WAVES * BWD_WORDS * sizeof(float) <= 65536, "static LDS of
 // tile buffers; the series themselves then hold the quantised integers as floats (the x operand of dW1)
 constexpr int DSER_WORDS = 356;
 // split form: words B lie a multiple of 64 words behind words A, so that one ds_read2st64_b32 fetches both
-constexpr int SPB_FWD = 704, SPB_BWD = 384;
-constexpr int FWD_ROW_SP3 = 1068;       // words per wave of the forward kernel in the split form (5 + 704 + 356, rounded up)
+#ifndef GEN_SPB_FWD
+#define GEN_SPB_FWD 704
+#endif
+constexpr int SPB_FWD = GEN_SPB_FWD, SPB_BWD = 384;
+constexpr int FWD_ROW_SP3 = (SER_BASE0 + SPB_FWD + DSER_WORDS + 3) / 4 * 4;   // words per wave of the forward kernel in the split form (1068)
 static_assert(SER_BASE0 + SPB_FWD >= SER_WORDS && SER_BASE0 + SPB_FWD + DSER_WORDS <= FWD_ROW_SP3, "words B behind the series region");
 static_assert((size_t)WAVES * (BWD_WORDS + DSER_WORDS) * sizeof(float) <= 65536, "63.9 KiB, two workgroups per CU");
 // (the split form of the float backward keeps two more sets, words A and B: 69.9 KiB of static LDS, two workgroups per CU)
